@@ -1,0 +1,78 @@
+/* TEST INFRASTRUCTURE ONLY.
+ * CPU restatement ("oracle") of the reference's PairHMM forward and HTC Smith-Waterman CPU paths.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so; the
+ * product path under acc_genomics_amd/ never does (it fails loudly when the HIP library is missing).
+ *
+ * Parity pin: tests/test_oracle_vs_reference.py checks every function here against the reference's
+ * own code compiled in place (oracle/_ref, see oracle/Makefile) and tests/golden/ holds vectors
+ * generated from that build by tools/make_golden.py.
+ */
+#ifndef ACCG_ORACLE_H
+#define ACCG_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- PairHMM ------------------------------------------------------------------------------- */
+#define ORC_M2M_SIZE (((254 + 1) * (254 + 2)) >> 1)  /* Context.h:22 */
+
+/* Context<float>/Context<double> tables (pairhmm/xlnx/host/Context.h:42-61,105-109,145-149). */
+void orc_phmm_tables_f(float* ph2pr128, float* m2m /*ORC_M2M_SIZE*/, float* init_const, float* log10_init);
+void orc_phmm_tables_d(double* ph2pr128, double* m2m /*ORC_M2M_SIZE*/, double* init_const, double* log10_init);
+
+/* compute_full_prob_baseline<T> (baseline_impl.cpp:8-104): raw likelihood x INITIAL_CONSTANT.
+ * sum_order 0 = scalar order (result += M+X per column, baseline_impl.cpp:90-92);
+ *           1 = AVX order (sum M and X separately over columns 1..H, add once, avx-pairhmm-template.h:328-343). */
+float  orc_phmm_forward_f32(int rslen, int haplen, const char* rs, const char* q, const char* qi, const char* qd,
+                            const char* qc, const char* hap, int sum_order);
+double orc_phmm_forward_f64(int rslen, int haplen, const char* rs, const char* q, const char* qi, const char* qd,
+                            const char* qc, const char* hap, int sum_order);
+/* FMA-contracted evaluation order used by the GPU "fast" mode (documented in DESIGN.md). */
+float  orc_phmm_forward_f32_fma(int rslen, int haplen, const char* rs, const char* q, const char* qi,
+                                const char* qd, const char* qc, const char* hap);
+
+/* Post-process of FalconPairHMM::computePairhmmAVX (FalconPairHMM.cpp:83-90):
+ * raw < 1e-28f -> log10(fp64 forward) - log10(2^1020), else (double)(log10f(raw) - log10f(2^120)). */
+double orc_phmm_finish(float raw, int rslen, int haplen, const char* rs, const char* q, const char* qi,
+                       const char* qd, const char* qc, const char* hap, int* rescued);
+
+/* reads x haps cross product, row-major [read][hap] (FalconPairHMM.cpp:69-95). Returns #rescued. */
+int orc_phmm_region(int n_reads, const int* rlen, const char* const* rs, const char* const* q, const char* const* qi,
+                    const char* const* qd, const char* const* qc, int n_haps, const int* hlen,
+                    const char* const* hap, float* out_raw, double* out_log10, int n_threads);
+
+/* P8 wire format (PairHMMHostInterface.cpp:175-255): int32 num; per read int32 len + 5 x len bytes
+ * (_b,_q,_i,_d,_c); per hap int32 len + len bytes. Returns bytes written / number decoded (-1 on error). */
+int64_t orc_phmm_serialize_reads(void* buf, int n, const int* len, const char* const* b, const char* const* q,
+                                 const char* const* qi, const char* const* qd, const char* const* qc);
+int64_t orc_phmm_serialize_haps(void* buf, int n, const int* len, const char* const* b);
+
+/* ---- HTC Smith-Waterman --------------------------------------------------------------------- */
+#define ORC_SW_SOFTCLIP 0
+#define ORC_SW_INDEL 1
+#define ORC_SW_LEADING_INDEL 2
+#define ORC_SW_IGNORE 3
+
+/* calculateMatrixOneBatch (FalconSW_AVX.cpp:1693-1823): sw, btrack are (refLen+1)x(altLen+1) row-major. */
+void orc_sw_fill(const char* ref, const char* alt, int refLen, int altLen, int strategy, int w_match,
+                 int w_mismatch, int w_open, int w_extend, int* sw, int* btrack);
+/* End-cell selection of calculateCigarOneBatch (FalconSW_AVX.cpp:2314-2339). */
+void orc_sw_endcell(const int* sw, int refLen, int altLen, int strategy, int* p1, int* p2, int* score,
+                    int* segment_length);
+/* Full calculateCigarOneBatch (:2303-2419): returns element count or -1; elements in final (forward) order. */
+int orc_sw_cigar(const int* sw, const int* btrack, int refLen, int altLen, int strategy, int max_el, int* cig_len,
+                 int* cig_state, int* alignment_offset);
+/* One pair end-to-end: fill + end cell + cigar. */
+int orc_sw_pair(const char* ref, const char* alt, int refLen, int altLen, int strategy, int w_match, int w_mismatch,
+                int w_open, int w_extend, int* score, int* p1, int* p2, int max_el, int* cig_len, int* cig_state,
+                int* alignment_offset);
+/* Score/end-cell only with rolling rows (no btrack) for many fixed-stride pairs; OpenMP over pairs. */
+void orc_sw_score_many(const char* refs, int ref_stride, const int* refLens, const char* alts, int alt_stride,
+                       const int* altLens, int n, int strategy, int w_match, int w_mismatch, int w_open,
+                       int w_extend, int* score, int* p1, int* p2, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

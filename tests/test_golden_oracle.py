@@ -1,0 +1,85 @@
+"""CPU oracle against the committed golden vectors (tests/golden, generated from the reference's own
+CPU code by tools/make_golden.py).  Runs without /root/reference."""
+import ctypes as C
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from acc_genomics_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PHMM = sorted(glob.glob(os.path.join(GOLD, "phmm_[!t]*.npz")))
+SW = sorted(glob.glob(os.path.join(GOLD, "sw_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(PHMM) >= 5 and len(SW) >= 3 and os.path.exists(os.path.join(GOLD, "phmm_tables.npz"))
+
+
+def test_tables_golden():
+    O = orc.oracle()
+    g = np.load(os.path.join(GOLD, "phmm_tables.npz"))
+    for tag, dt, ct, fn in (("f32", np.float32, orc.f32p, O.orc_phmm_tables_f), ("f64", np.float64, orc.f64p, O.orc_phmm_tables_d)):
+        p, m, i, l = np.zeros(128, dt), np.zeros(32640, dt), np.zeros(1, dt), np.zeros(1, dt)
+        fn(orc.ptr(p, ct), orc.ptr(m, ct), orc.ptr(i, ct), orc.ptr(l, ct))
+        assert p.tobytes() == g["ph2pr_" + tag].tobytes()
+        assert m[:8256].tobytes() == g["m2m_head_" + tag].tobytes()
+        assert hashlib.sha256(m.tobytes()).digest() == g["m2m_sha256_" + tag].tobytes()
+        assert i.tobytes() == g["init_" + tag].tobytes() and l.tobytes() == g["log10_init_" + tag].tobytes()
+
+
+@pytest.mark.parametrize("path", PHMM, ids=[os.path.basename(p)[:-4] for p in PHMM])
+def test_phmm_golden(path):
+    O = orc.oracle()
+    g = np.load(path)
+    reads, haps = synth.deserialize_reads(g["reads_ser"]), synth.deserialize_haps(g["haps_ser"])
+    assert len(reads) == int(g["n_reads"]) and len(haps) == int(g["n_haps"])
+    rl, hl, keep = orc.region_args(reads, haps)
+    n = len(reads) * len(haps)
+    raw, l10 = np.zeros(n, np.float32), np.zeros(n, np.float64)
+    resc = O.orc_phmm_region(len(reads), orc.ptr(rl, orc.i32p), *keep[:5], len(haps), orc.ptr(hl, orc.i32p), keep[5],
+                             orc.ptr(raw, orc.f32p), orc.ptr(l10, orc.f64p), 2)
+    # bit-exact against the reference's scalar baseline built without FMA contraction
+    assert raw.tobytes() == g["raw_scalar_nofma"].tobytes()
+    assert l10.tobytes() == g["log10_scalar_nofma"].tobytes()
+    assert resc == int(g["rescued_scalar_nofma"])
+    # and inside the 1e-5 budget of the judged path (computePairhmmAVX as the reference builds it)
+    rel = np.abs(l10 - g["log10_avx"]) / np.abs(g["log10_avx"])
+    assert rel.max() < 2e-6
+    ok = g["raw_avx"] > 1e-28
+    assert (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < 1e-5
+
+
+@pytest.mark.parametrize("path", SW, ids=[os.path.basename(p)[:-4] for p in SW])
+def test_sw_golden(path):
+    O = orc.oracle()
+    g = np.load(path)
+    refs, alts = g["refs"], g["alts"]
+    for s in range(4):
+        for k in range(refs.shape[0]):
+            sc, p1, p2, off, cig, n = orc.sw_pair(O, refs[k].tobytes(), alts[k].tobytes(), s)
+            assert (sc, p1, p2, off, n) == (g["score"][s, k], g["p1"][s, k], g["p2"][s, k], g["offset"][s, k], g["n_el"][s, k])
+            assert cig == list(zip(g["cig_len"][s, k, :n].tolist(), g["cig_state"][s, k, :n].tolist()))
+
+
+def test_serialize_layout():
+    """P8 wire format, hand-derived from PairHMMHostInterface.cpp:175-206."""
+    O = orc.oracle()
+    reads = [dict(b=b"ACG", q=b"\x1e\x1f\x20", i=b"\x28\x28\x28", d=b"\x29\x29\x29", c=b"\x0a\x0a\x0a"),
+             dict(b=b"T", q=b"\x05", i=b"\x06", d=b"\x07", c=b"\x08")]
+    haps = [b"ACGTN", b"GG"]
+    want_r = (b"\x02\0\0\0" + b"\x03\0\0\0" + b"ACG" + b"\x1e\x1f\x20" + b"\x28\x28\x28" + b"\x29\x29\x29" + b"\x0a\x0a\x0a"
+              + b"\x01\0\0\0" + b"T\x05\x06\x07\x08")
+    want_h = b"\x02\0\0\0" + b"\x05\0\0\0ACGTN" + b"\x02\0\0\0GG"
+    assert synth.serialize_reads(reads) == want_r and synth.serialize_haps(haps) == want_h
+    rl, hl, keep = orc.region_args(reads, haps)
+    buf = C.create_string_buffer(256)
+    n = O.orc_phmm_serialize_reads(buf, 2, orc.ptr(rl, orc.i32p), *keep[:5])
+    assert buf.raw[:n] == want_r
+    n = O.orc_phmm_serialize_haps(buf, 2, orc.ptr(hl, orc.i32p), keep[5])
+    assert buf.raw[:n] == want_h
+    assert synth.deserialize_reads(want_r) == reads and synth.deserialize_haps(want_h) == haps
