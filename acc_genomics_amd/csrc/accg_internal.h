@@ -1,0 +1,39 @@
+// Internal host-side declarations shared by the translation units of libaccg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/accg.h"
+#include "phmm_dev.h"
+
+namespace accg {
+
+void set_hip_error(hipError_t e, const char* what);
+
+#define ACCG_HIP(call)                                                         \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) { ::accg::set_hip_error(e_, #call); return ACCG_ERR_HIP; } \
+  } while (0)
+
+// Host copies of the Context<T> tables (pairhmm/xlnx/host/Context.h) + the derived per-quality
+// factors the kernels read.
+struct HostTables {
+  float ph_f[128], omph_f[128], phd3_f[128], m2m_f[8256], init_f, log10_init_f;
+  double ph_d[128], omph_d[128], phd3_d[128], m2m_d[8256], init_d, log10_init_d;
+};
+const HostTables& host_tables();
+
+}  // namespace accg
+
+struct accg_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  accg::PhmmTables<float> tab_f{};
+  accg::PhmmTables<double> tab_d{};
+  void* tab_mem = nullptr;      // one allocation behind both table sets
+  char name[128] = {0};
+  int n_cu = 0;
+};

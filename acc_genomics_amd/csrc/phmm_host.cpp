@@ -1,0 +1,450 @@
+// Host side of the PairHMM path: context, wire-format parsing, job partitioning, launches, results.
+// Boundary it stands in for: compute_fpga (pairhmm/host/PairHMMFpga.cpp:125-162), the Blaze task's
+// prepare()/compute() (pairhmm/task/xlnx/PairHMMTask.cpp:27-143) and the pair loop + post-process of
+// FalconPairHMM::computePairhmmAVX (pairhmm/xlnx/host/FalconPairHMM.cpp:69-95).
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <numeric>
+#include "accg_internal.h"
+
+using namespace accg;
+
+namespace accg {
+static thread_local std::string g_hip_err;
+void set_hip_error(hipError_t e, const char* what) {
+  g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+}  // namespace accg
+
+extern "C" const char* accg_last_hip_error(void) { return g_hip_err.c_str(); }
+
+extern "C" const char* accg_strerror(int st) {
+  switch (st) {
+    case ACCG_OK: return "ok";
+    case ACCG_ERR_NO_DEVICE: return "no gfx950 HIP device";
+    case ACCG_ERR_NOT_INITIALISED: return "context not initialised";
+    case ACCG_ERR_BAD_ARG: return "bad argument";
+    case ACCG_ERR_BAD_WIRE: return "malformed serialized reads/haps";
+    case ACCG_ERR_BAD_BASE: return "base other than A,C,G,T,N";
+    case ACCG_ERR_EMPTY_SEQ: return "zero-length read or haplotype";
+    case ACCG_ERR_TOO_LONG: return "sequence longer than the kernel supports";
+    case ACCG_ERR_HIP: return "HIP runtime error";
+    case ACCG_ERR_NOMEM: return "out of memory";
+  }
+  return "unknown status";
+}
+
+// ---- context ------------------------------------------------------------------------------------
+extern "C" int accg_init(int device, accg_ctx** out) {
+  if (!out) return ACCG_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ACCG_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  ACCG_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ACCG_ERR_NO_DEVICE;   // code objects are gfx950 only
+  ACCG_HIP(hipSetDevice(device));
+  accg_ctx* c = new accg_ctx;
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, c->n_cu);
+  ACCG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  ACCG_HIP(hipEventCreate(&c->ev0));
+  ACCG_HIP(hipEventCreate(&c->ev1));
+  const HostTables& t = host_tables();
+  const size_t nf = 128 * 3 + 8256, bytes = nf * sizeof(float) + nf * sizeof(double);
+  ACCG_HIP(hipMalloc(&c->tab_mem, bytes));
+  double* d = (double*)c->tab_mem;
+  float* f = (float*)(d + nf);
+  auto up = [&](void* dst, const void* src, size_t b) { return hipMemcpy(dst, src, b, hipMemcpyHostToDevice); };
+  ACCG_HIP(up(d, t.ph_d, 128 * 8)); ACCG_HIP(up(d + 128, t.omph_d, 128 * 8)); ACCG_HIP(up(d + 256, t.phd3_d, 128 * 8));
+  ACCG_HIP(up(d + 384, t.m2m_d, 8256 * 8));
+  ACCG_HIP(up(f, t.ph_f, 128 * 4)); ACCG_HIP(up(f + 128, t.omph_f, 128 * 4)); ACCG_HIP(up(f + 256, t.phd3_f, 128 * 4));
+  ACCG_HIP(up(f + 384, t.m2m_f, 8256 * 4));
+  c->tab_d = {d, d + 128, d + 256, d + 384, t.init_d};
+  c->tab_f = {f, f + 128, f + 256, f + 384, t.init_f};
+  *out = c;
+  return ACCG_OK;
+}
+
+extern "C" void accg_shutdown(accg_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->tab_mem) hipFree(c->tab_mem);
+  delete c;
+}
+extern "C" void* accg_stream(accg_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int accg_device_name(accg_ctx* c, char* buf, size_t n) {
+  if (!c || !buf || !n) return ACCG_ERR_BAD_ARG;
+  snprintf(buf, n, "%s", c->name);
+  return ACCG_OK;
+}
+extern "C" void accg_counters_pack(const accg_counters* c, uint64_t out[4]) {
+  out[0] = c->cells; out[1] = c->pairs; out[2] = c->kernel_ns; out[3] = c->rescued;
+}
+// Context<T> tables as the device sees them (tests pin them to the golden table fixture).
+extern "C" void accg_phmm_tables_f32(float* ph128, float* m2m8256, float* init, float* log10_init) {
+  const HostTables& t = host_tables();
+  memcpy(ph128, t.ph_f, sizeof t.ph_f); memcpy(m2m8256, t.m2m_f, sizeof t.m2m_f); *init = t.init_f; *log10_init = t.log10_init_f;
+}
+extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* init, double* log10_init) {
+  const HostTables& t = host_tables();
+  memcpy(ph128, t.ph_d, sizeof t.ph_d); memcpy(m2m8256, t.m2m_d, sizeof t.m2m_d); *init = t.init_d; *log10_init = t.log10_init_d;
+}
+
+// ---- batch --------------------------------------------------------------------------------------
+namespace {
+
+struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
+struct KLaunch { int K; uint32_t work0, n_work; };
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count;
+    if (count == 0) return ACCG_OK;
+    ACCG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    return ACCG_OK;
+  }
+  int upload(const std::vector<T>& v, hipStream_t s) {
+    int st = alloc(v.size());
+    if (st != ACCG_OK || v.empty()) return st;
+    ACCG_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return ACCG_OK;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+bool valid_base_lut(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N'; }
+
+}  // namespace
+
+struct accg_phmm_batch {
+  accg_ctx* ctx = nullptr;
+  std::vector<Region> regions;
+  std::vector<SeqRef> rd, hp;
+  std::vector<uint32_t> rd_out, hp_local, hap_ids;
+  std::vector<PhmmWork> work;
+  std::vector<KLaunch> launches;
+  uint64_t pairs = 0, cells = 0, algo_bytes = 0;
+  DevBuf<uint8_t> d_rblob, d_hblob;
+  DevBuf<SeqRef> d_rd, d_hp;
+  DevBuf<uint32_t> d_rd_out, d_hp_local, d_hap_ids;
+  DevBuf<PhmmWork> d_work;
+  DevBuf<float> d_out;
+  DevBuf<double> d_out64;
+  DevBuf<unsigned long long> d_nresc;
+  uint64_t last_kernel_ns = 0;
+};
+
+namespace {
+
+// Wire format (pairhmm/interface/PairHMMHostInterface.cpp:175-206): returns number of records, fills refs
+// with offsets relative to `base_off` (position of this blob inside the concatenated device blob).
+int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs) {
+  if (bytes < 4) return ACCG_ERR_BAD_WIRE;
+  int32_t n; memcpy(&n, p, 4);
+  if (n < 0) return ACCG_ERR_BAD_WIRE;
+  size_t pos = 4;
+  for (int i = 0; i < n; i++) {
+    if (pos + 4 > bytes) return ACCG_ERR_BAD_WIRE;
+    int32_t len; memcpy(&len, p + pos, 4); pos += 4;
+    if (len < 0 || pos + 5 * (size_t)len > bytes) return ACCG_ERR_BAD_WIRE;
+    if (len == 0) return ACCG_ERR_EMPTY_SEQ;
+    if (len > ACCG_PHMM_MAX_READ) return ACCG_ERR_TOO_LONG;
+    for (int k = 0; k < len; k++) if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
+    refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
+    pos += 5 * (size_t)len;
+  }
+  return n;
+}
+int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs) {
+  if (bytes < 4) return ACCG_ERR_BAD_WIRE;
+  int32_t n; memcpy(&n, p, 4);
+  if (n < 0) return ACCG_ERR_BAD_WIRE;
+  size_t pos = 4;
+  for (int i = 0; i < n; i++) {
+    if (pos + 4 > bytes) return ACCG_ERR_BAD_WIRE;
+    int32_t len; memcpy(&len, p + pos, 4); pos += 4;
+    if (len < 0 || pos + (size_t)len > bytes) return ACCG_ERR_BAD_WIRE;
+    if (len == 0) return ACCG_ERR_EMPTY_SEQ;
+    if (len > ACCG_PHMM_MAX_HAP) return ACCG_ERR_TOO_LONG;
+    for (int k = 0; k < len; k++) if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
+    refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
+    pos += (size_t)len;
+  }
+  return n;
+}
+
+inline int k_for(uint32_t read_len) { return (int)((read_len + 1 + 15) / 16); }   // one row reserved as "row 0"
+
+// Cuts every region into jobs = (four reads of similar length) x (a run of haplotypes).
+void partition(accg_phmm_batch& b) {
+  // how many wavefronts we would like in flight: enough for ~4 per SIMD on every CU
+  const uint64_t target_jobs = (uint64_t)std::max(b.ctx->n_cu, 1) * 4 * 4;
+  struct Job { PhmmWork w; int K; uint64_t cost; };
+  std::vector<Job> jobs;
+  uint64_t total_quads = 0;
+  for (const Region& r : b.regions) total_quads += (r.n_reads + 3) / 4;
+  for (const Region& r : b.regions) {
+    if (r.n_reads == 0 || r.n_haps == 0) continue;
+    // reads by descending length so that the four reads of a wavefront need the same K
+    std::vector<uint32_t> order(r.n_reads);
+    std::iota(order.begin(), order.end(), r.read0);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b.rd[x].len > b.rd[y].len; });
+    const uint32_t n_quads = (r.n_reads + 3) / 4;
+    // haplotype runs: capacity limits first, then split further while the chip is under-filled
+    uint64_t stream_total = 0;
+    for (uint32_t h = 0; h < r.n_haps; h++) stream_total += b.hp[r.hap0 + h].len + 1;
+    uint64_t want_chunks = (target_jobs + total_quads - 1) / std::max<uint64_t>(total_quads, 1);
+    uint64_t min_steps = 512;   // below this the 15-step fill and the prologue start to show
+    uint64_t max_chunks_by_len = std::max<uint64_t>(1, stream_total / min_steps);
+    want_chunks = std::min<uint64_t>(std::min<uint64_t>(want_chunks, max_chunks_by_len), r.n_haps);
+    uint64_t budget = std::max<uint64_t>((stream_total + want_chunks - 1) / std::max<uint64_t>(want_chunks, 1), 1);
+    budget = std::min<uint64_t>(budget, PHMM_STREAM_MAX - 1);
+    struct Chunk { uint32_t ids0, n; uint64_t steps; };
+    std::vector<Chunk> chunks;
+    uint32_t h = 0;
+    while (h < r.n_haps) {
+      uint32_t ids0 = (uint32_t)b.hap_ids.size(), n = 0;
+      uint64_t len = 1;   // terminal bubble
+      while (h < r.n_haps && n < (uint32_t)PHMM_HAPS_MAX) {
+        uint64_t add = b.hp[r.hap0 + h].len + 1;
+        if (n > 0 && (len + add > budget)) break;          // budget is soft for a single long haplotype...
+        if (len + add > (uint64_t)PHMM_STREAM_MAX) break;  // ...the LDS stream is not (ACCG_PHMM_MAX_HAP < PHMM_STREAM_MAX)
+        b.hap_ids.push_back(r.hap0 + h);
+        len += add; n++; h++;
+      }
+      chunks.push_back({ids0, n, len + 15});
+    }
+    for (uint32_t q = 0; q < n_quads; q++) {
+      PhmmWork w;
+      uint32_t maxlen = 0; uint64_t rows = 0;
+      for (int g = 0; g < PHMM_GROUPS; g++) {
+        uint32_t i = q * 4 + g;
+        w.read[g] = i < r.n_reads ? order[i] : PHMM_NO_READ;
+        if (i < r.n_reads) { maxlen = std::max(maxlen, b.rd[order[i]].len); rows += b.rd[order[i]].len; }
+      }
+      w.pad_[0] = w.pad_[1] = 0;
+      for (const Chunk& c : chunks) {
+        w.hap_off = c.ids0; w.n_haps = c.n;
+        jobs.push_back({w, k_for(maxlen), c.steps * (uint64_t)k_for(maxlen)});
+      }
+    }
+  }
+  // one launch per K; inside a launch the longest jobs go first so the tail is short
+  std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.K != y.K ? x.K > y.K : x.cost > y.cost; });
+  b.work.resize(jobs.size());
+  for (size_t i = 0; i < jobs.size(); i++) {
+    b.work[i] = jobs[i].w;
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K) b.launches.push_back({jobs[i].K, (uint32_t)i, 0});
+    b.launches.back().n_work++;
+  }
+}
+
+template <typename T>
+PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab) {
+  PhmmArgs<T> a;
+  a.rblob = b.d_rblob.p; a.hblob = b.d_hblob.p; a.rd = b.d_rd.p; a.rd_out = b.d_rd_out.p; a.hp = b.d_hp.p;
+  a.hp_local = b.d_hp_local.p; a.hap_ids = b.d_hap_ids.p; a.work = b.d_work.p; a.out = out;
+  a.raw = b.d_out.p; a.n_rescued = b.d_nresc.p; a.tab = tab;
+  return a;
+}
+
+int launch_f32(accg_phmm_batch* b, int mode) {
+  PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
+  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f32(l.K, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, b->ctx->stream));
+  return ACCG_OK;
+}
+int launch_rescue(accg_phmm_batch* b) {
+  ACCG_HIP(hipMemsetAsync(b->d_nresc.p, 0, sizeof(unsigned long long), b->ctx->stream));
+  PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
+  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_rescue_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+  return ACCG_OK;
+}
+
+}  // namespace
+
+extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* const* reads_ser,
+                                      const size_t* reads_bytes, const void* const* haps_ser,
+                                      const size_t* haps_bytes, accg_phmm_batch** out) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out || n_regions < 0 || (n_regions > 0 && (!reads_ser || !reads_bytes || !haps_ser || !haps_bytes))) return ACCG_ERR_BAD_ARG;
+  *out = nullptr;
+  ACCG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<accg_phmm_batch> b(new accg_phmm_batch);
+  b->ctx = ctx;
+  uint64_t roff = 0, hoff = 0;
+  for (int i = 0; i < n_regions; i++) { roff += reads_bytes[i]; hoff += haps_bytes[i]; }
+  if (roff >= (1ull << 32) || hoff >= (1ull << 32)) return ACCG_ERR_TOO_LONG;   // 32-bit blob offsets
+  roff = hoff = 0;
+  for (int i = 0; i < n_regions; i++) {
+    Region r;
+    r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
+    int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd);
+    if (nr < 0) return nr;
+    int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp);
+    if (nh < 0) return nh;
+    r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;
+    uint64_t rsum = 0, hsum = 0;
+    for (int k = 0; k < nr; k++) rsum += b->rd[r.read0 + k].len;
+    for (int k = 0; k < nh; k++) hsum += b->hp[r.hap0 + k].len;
+    b->cells += rsum * hsum;
+    for (int k = 0; k < nr; k++) {
+      uint64_t o = r.out0 + (uint64_t)k * nh;
+      if (o + nh >= (1ull << 32)) return ACCG_ERR_TOO_LONG;   // 32-bit output indices
+      b->rd_out.push_back((uint32_t)o);
+    }
+    for (int k = 0; k < nh; k++) b->hp_local.push_back((uint32_t)k);
+    b->pairs += (uint64_t)nr * nh;
+    b->regions.push_back(r);
+    roff += reads_bytes[i]; hoff += haps_bytes[i];
+  }
+  b->algo_bytes = roff + hoff + 4 * b->pairs;   // blobs in, one float per pair out
+  partition(*b);
+  hipStream_t s = ctx->stream;
+  int st;
+  if ((st = b->d_rblob.alloc(roff + 16)) != ACCG_OK) return st;
+  if ((st = b->d_hblob.alloc(hoff + 16)) != ACCG_OK) return st;
+  roff = hoff = 0;
+  for (int i = 0; i < n_regions; i++) {
+    if (reads_bytes[i]) ACCG_HIP(hipMemcpyAsync(b->d_rblob.p + roff, reads_ser[i], reads_bytes[i], hipMemcpyHostToDevice, s));
+    if (haps_bytes[i]) ACCG_HIP(hipMemcpyAsync(b->d_hblob.p + hoff, haps_ser[i], haps_bytes[i], hipMemcpyHostToDevice, s));
+    roff += reads_bytes[i]; hoff += haps_bytes[i];
+  }
+  if ((st = b->d_rd.upload(b->rd, s)) != ACCG_OK) return st;
+  if ((st = b->d_hp.upload(b->hp, s)) != ACCG_OK) return st;
+  if ((st = b->d_rd_out.upload(b->rd_out, s)) != ACCG_OK) return st;
+  if ((st = b->d_hp_local.upload(b->hp_local, s)) != ACCG_OK) return st;
+  if ((st = b->d_hap_ids.upload(b->hap_ids, s)) != ACCG_OK) return st;
+  if ((st = b->d_work.upload(b->work, s)) != ACCG_OK) return st;
+  if ((st = b->d_out.alloc(b->pairs + 1)) != ACCG_OK) return st;
+  if ((st = b->d_out64.alloc(b->pairs + 1)) != ACCG_OK) return st;
+  if ((st = b->d_nresc.alloc(1)) != ACCG_OK) return st;
+  ACCG_HIP(hipMemsetAsync(b->d_out.p, 0, (b->pairs + 1) * sizeof(float), s));
+  ACCG_HIP(hipMemsetAsync(b->d_out64.p, 0, (b->pairs + 1) * sizeof(double), s));
+  ACCG_HIP(hipMemsetAsync(b->d_nresc.p, 0, sizeof(unsigned long long), s));
+  ACCG_HIP(hipStreamSynchronize(s));   // the caller's host buffers may go away after this returns
+  *out = b.release();
+  return ACCG_OK;
+}
+
+extern "C" uint64_t accg_phmm_batch_pairs(const accg_phmm_batch* b) { return b ? b->pairs : 0; }
+extern "C" uint64_t accg_phmm_batch_cells(const accg_phmm_batch* b) { return b ? b->cells : 0; }
+extern "C" uint64_t accg_phmm_batch_algorithmic_bytes(const accg_phmm_batch* b) { return b ? b->algo_bytes : 0; }
+extern "C" uint64_t accg_phmm_batch_jobs(const accg_phmm_batch* b) { return b ? b->work.size() : 0; }
+
+extern "C" int accg_phmm_batch_run(accg_phmm_batch* b, int mode) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  int st = launch_f32(b, mode);
+  if (st != ACCG_OK) return st;
+  return launch_rescue(b);
+}
+
+// fp64 over every pair (FalconPairHMM::computePairhmmAVX with use_double = true, FalconPairHMM.cpp:82);
+// results land in the fp64 buffer and are fetched with accg_phmm_batch_results_f64.
+extern "C" int accg_phmm_batch_run_f64(accg_phmm_batch* b) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
+  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+  return ACCG_OK;
+}
+extern "C" int accg_phmm_batch_results_f64(accg_phmm_batch* b, double* out_raw64) {
+  if (!b || !out_raw64) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  if (b->pairs) ACCG_HIP(hipMemcpy(out_raw64, b->d_out64.p, b->pairs * sizeof(double), hipMemcpyDeviceToHost));
+  return ACCG_OK;
+}
+
+// what: 0 = whole run (fp32 pass + rescue pass), 1 = fp32 pass only (the dominant kernel)
+extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int warmup, int iters, float* ms_per_run) {
+  if (!b || !ms_per_run || iters <= 0 || warmup < 0) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  accg_ctx* c = b->ctx;
+  int st;
+  for (int i = 0; i < warmup; i++) {
+    if ((st = launch_f32(b, mode)) != ACCG_OK) return st;
+    if (what == 0 && (st = launch_rescue(b)) != ACCG_OK) return st;
+  }
+  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < iters; i++) {
+    if ((st = launch_f32(b, mode)) != ACCG_OK) return st;
+    if (what == 0 && (st = launch_rescue(b)) != ACCG_OK) return st;
+  }
+  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
+  ACCG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_run = ms / iters;
+  b->last_kernel_ns = (uint64_t)((double)ms / iters * 1e6);
+  if (what != 0) { if ((st = launch_rescue(b)) != ACCG_OK) return st; }   // leave the buffers consistent
+  return ACCG_OK;
+}
+extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, float* ms_per_run) {
+  return accg_phmm_batch_time2(b, mode, 0, warmup, iters, ms_per_run);
+}
+
+extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* cnt) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  unsigned long long nresc = 0;
+  ACCG_HIP(hipMemcpy(&nresc, b->d_nresc.p, sizeof nresc, hipMemcpyDeviceToHost));
+  std::vector<float> tmp;
+  float* raw = out_raw;
+  if (!raw && out_log10) { tmp.resize(b->pairs); raw = tmp.data(); }
+  if (raw && b->pairs) ACCG_HIP(hipMemcpy(raw, b->d_out.p, b->pairs * sizeof(float), hipMemcpyDeviceToHost));
+  if (out_log10 && b->pairs) {
+    std::vector<double> r64;
+    if (nresc) { r64.resize(b->pairs); ACCG_HIP(hipMemcpy(r64.data(), b->d_out64.p, b->pairs * sizeof(double), hipMemcpyDeviceToHost)); }
+    const HostTables& t = host_tables();
+    // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
+    for (uint64_t i = 0; i < b->pairs; i++) {
+      if (raw[i] < PHMM_MIN_ACCEPTED) out_log10[i] = log10(r64[i]) - t.log10_init_d;
+      else out_log10[i] = (double)(log10f(raw[i]) - t.log10_init_f);
+    }
+  }
+  if (cnt) { cnt->cells = b->cells; cnt->pairs = b->pairs; cnt->kernel_ns = b->last_kernel_ns; cnt->rescued = nresc; }
+  return ACCG_OK;
+}
+
+extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  b->d_rblob.release(); b->d_hblob.release(); b->d_rd.release(); b->d_hp.release(); b->d_rd_out.release();
+  b->d_hp_local.release(); b->d_hap_ids.release(); b->d_work.release(); b->d_out.release(); b->d_out64.release();
+  b->d_nresc.release();
+  delete b;
+}
+
+extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
+                                size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* cnt) {
+  accg_phmm_batch* b = nullptr;
+  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
+  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
+  int st = accg_phmm_batch_create(ctx, 1, rs, rb, hs, hb, &b);
+  if (st != ACCG_OK) return st;
+  hipEventRecord(ctx->ev0, ctx->stream);
+  st = accg_phmm_batch_run(b, mode);
+  hipEventRecord(ctx->ev1, ctx->stream);
+  if (st == ACCG_OK) {
+    if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
+      float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+      b->last_kernel_ns = (uint64_t)((double)ms * 1e6);
+    }
+    st = accg_phmm_batch_results(b, out_raw, out_log10, cnt);
+  }
+  accg_phmm_batch_destroy(b);
+  return st;
+}

@@ -1,0 +1,100 @@
+/* acc_genomics_amd -- C ABI of the MI355X (gfx950) hot path: PairHMM forward + HTC Smith-Waterman.
+ *
+ * Every entry point is plain C (pointers + sizes, int status, nothing thrown across the boundary,
+ * caller owns every buffer it passes).  Each one names the reference interface it stands in for;
+ * INTEGRATION.md shows the C++ wrappers a maintainer of the reference would add on top.
+ *
+ * There is no CPU fallback behind this ABI: if no gfx950 device is present, accg_init() fails with
+ * ACCG_ERR_NO_DEVICE and every other call with ACCG_ERR_NOT_INITIALISED.
+ */
+#ifndef ACCG_H
+#define ACCG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  ACCG_OK = 0,
+  ACCG_ERR_NO_DEVICE = -1,       /* no HIP device / not gfx950 */
+  ACCG_ERR_NOT_INITIALISED = -2,
+  ACCG_ERR_BAD_ARG = -3,
+  ACCG_ERR_BAD_WIRE = -4,        /* serialized reads/haps blob inconsistent with its size */
+  ACCG_ERR_BAD_BASE = -5,        /* base other than A,C,G,T,N (SURVEY.md appendix B caveat 1) */
+  ACCG_ERR_EMPTY_SEQ = -6,       /* zero-length read or haplotype (reference divides by haplen) */
+  ACCG_ERR_TOO_LONG = -7,        /* read > ACCG_PHMM_MAX_READ or hap > ACCG_PHMM_MAX_HAP; SW length > ACCG_SW_MAX_LEN */
+  ACCG_ERR_HIP = -8,             /* a HIP runtime call failed; see accg_last_hip_error() */
+  ACCG_ERR_NOMEM = -9
+};
+
+#define ACCG_PHMM_MAX_READ 255   /* rows held in registers: 16 lanes x 16 rows, one row reserved */
+#define ACCG_PHMM_MAX_HAP 4000   /* one haplotype must fit the per-wave LDS stream */
+#define ACCG_SW_MAX_LEN 1535     /* htc-sw/host/common.h:13 MAX_SEQ_LENGTH - 1 */
+
+/* arithmetic mode of the fp32 PairHMM kernel */
+#define ACCG_PHMM_FAST 0    /* FMA-contracted recurrence (default) */
+#define ACCG_PHMM_STRICT 1  /* operation order of compute_full_prob_baseline<float>, no contraction: bit-exact with it */
+
+typedef struct accg_ctx accg_ctx;
+typedef struct accg_phmm_batch accg_phmm_batch;
+typedef struct accg_sw_batch accg_sw_batch;
+
+typedef struct {
+  uint64_t cells;        /* sum of read_len * hap_len over all pairs (the reference's GCUPS numerator,
+                            pairhmm/xlnx/pairhmm_test.cpp:280-289) */
+  uint64_t pairs;
+  uint64_t kernel_ns;    /* device time of the last run, fp32 pass + fp64 rescue pass (hipEvents) */
+  uint64_t rescued;      /* pairs recomputed in fp64 (raw < 1e-28f, FalconPairHMM.cpp:84) */
+} accg_counters;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int accg_init(int device, accg_ctx** out);
+void accg_shutdown(accg_ctx* ctx);
+const char* accg_strerror(int status);
+const char* accg_last_hip_error(void);
+/* the stream every launch of this context goes to (a hipStream_t) */
+void* accg_stream(accg_ctx* ctx);
+int accg_device_name(accg_ctx* ctx, char* buf, size_t n);
+
+/* ---- PairHMM --------------------------------------------------------------------------------
+ * One "region" = all reads x all haplotypes, given in the reference's wire format
+ * (pairhmm/interface/PairHMMHostInterface.cpp:175-206: int32 num; per read int32 len + _b,_q,_i,_d,_c;
+ * per hap int32 len + bases).  Output index = read * n_haps + hap, as compute_fpga returns it
+ * (pairhmm/host/PairHMMFpga.cpp:125-162) and FalconPairHMM::computePairhmmAVX fills it
+ * (pairhmm/xlnx/host/FalconPairHMM.cpp:69-95). */
+
+/* Replaces compute_fpga() (pairhmm/host/PairHMMFpga.h:16-20) and the prepare()+compute() pair of the
+ * Blaze task (pairhmm/task/xlnx/PairHMMTask.cpp:27-143): raw fp32 likelihood x 2^120 per pair.
+ * out_log10 (nullable) additionally receives the final log10 likelihood with the fp64 rescue applied,
+ * i.e. the output of FalconPairHMM::computePairhmm / PairHMMWorker::getOutput
+ * (pairhmm/client/PairHMMWorker.cpp:157-197). */
+int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
+                     size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* counters);
+
+/* Device-resident multi-region batch: upload once, run many times (pipelines, bench.py).
+ * Regions are independent; outputs are concatenated in region order, each region row-major. */
+int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* const* reads_ser, const size_t* reads_bytes,
+                           const void* const* haps_ser, const size_t* haps_bytes, accg_phmm_batch** out);
+uint64_t accg_phmm_batch_pairs(const accg_phmm_batch* b);
+uint64_t accg_phmm_batch_cells(const accg_phmm_batch* b);
+/* bytes the kernels must move for this batch: wire blobs in + 4 B per pair out */
+uint64_t accg_phmm_batch_algorithmic_bytes(const accg_phmm_batch* b);
+/* fp32 pass over every pair, then the fp64 rescue pass; asynchronous on accg_stream(). */
+int accg_phmm_batch_run(accg_phmm_batch* b, int mode);
+/* `iters` back-to-back runs bracketed by hipEvents on the launch stream; returns mean ms per run. */
+int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, float* ms_per_run);
+/* waits for the stream, copies results back; either pointer may be NULL */
+int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* counters);
+void accg_phmm_batch_destroy(accg_phmm_batch* b);
+
+/* ---- counters (multi-GPU) ---------------------------------------------------------------------
+ * Packs counters into the uint64[4] {cells, pairs, kernel_ns, rescued} vector that the ranks
+ * all-reduce over RCCL; the collective itself is issued by the host harness
+ * (torch.distributed, backend "nccl" == RCCL) -- no data-path collective exists. */
+void accg_counters_pack(const accg_counters* c, uint64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

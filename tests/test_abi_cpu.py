@@ -1,0 +1,61 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/accg.h declares,
+refuses to run without a GPU (no silent fallback), and its host-side tables match the golden ones."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import acc_genomics_amd as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _declared_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names |= set(re.findall(r"\b(accg_[a-z0-9_]+|FalconSWFPGA_[a-z]+|compute_fpga)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = A.load()
+    decl = _declared_symbols()
+    assert len(decl) >= 15
+    for n in sorted(decl):
+        assert hasattr(L, n), "libaccg_hip.so does not export %s" % n
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(A.AccgError) as e:
+        A.Context(0)
+    assert e.value.status == -1
+
+
+def test_product_never_links_the_oracle():
+    out = os.popen("ldd %s 2>/dev/null; nm -D %s | grep -i ' orc_\\| ref_' " % (A.lib_path(), A.lib_path())).read()
+    assert "liboracle" not in out and "libaccg_ref" not in out and "orc_" not in out
+    for dp, _, fns in os.walk(os.path.join(ROOT, "acc_genomics_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "liboracle" not in txt and "oracle/" not in txt.replace("oracle/_ref", "oracle/"), fn
+
+
+def test_host_tables_match_golden():
+    L = A.load()
+    g = np.load(os.path.join(GOLD, "phmm_tables.npz"))
+    for tag, dt, fn in (("f32", np.float32, L.accg_phmm_tables_f32), ("f64", np.float64, L.accg_phmm_tables_f64)):
+        ph, m2m, init, l10 = np.zeros(128, dt), np.zeros(8256, dt), np.zeros(1, dt), np.zeros(1, dt)
+        fn(ph.ctypes.data, m2m.ctypes.data, init.ctypes.data, l10.ctypes.data)
+        assert ph.tobytes() == g["ph2pr_" + tag].tobytes()
+        assert m2m.tobytes() == g["m2m_head_" + tag].tobytes()
+        assert init.tobytes() == g["init_" + tag].tobytes() and l10.tobytes() == g["log10_init_" + tag].tobytes()

@@ -1,0 +1,169 @@
+"""PairHMM parity on the GPU, through the C ABI (acc_genomics_amd/libaccg_hip.so).
+
+Bars (BASELINE.json): fp32 log-likelihoods within 1e-5 relative of the reference CPU path.  The
+strict mode is additionally required to be BIT-EXACT with compute_full_prob_baseline<float>
+(reference built without FMA contraction; golden vectors raw_scalar_nofma) and the fp64 rescue
+bit-exact with compute_full_prob_baseline<double>."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import acc_genomics_amd as A
+from acc_genomics_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PHMM = sorted(glob.glob(os.path.join(GOLD, "phmm_[!t]*.npz")))
+REL_TOL = 1e-5   # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = A.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_region(reads, haps, threads=8):
+    O = orc.oracle()
+    rl, hl, keep = orc.region_args(reads, haps)
+    n = len(reads) * len(haps)
+    raw, l10 = np.zeros(n, np.float32), np.zeros(n, np.float64)
+    resc = O.orc_phmm_region(len(reads), orc.ptr(rl, orc.i32p), *keep[:5], len(haps), orc.ptr(hl, orc.i32p), keep[5],
+                             orc.ptr(raw, orc.f32p), orc.ptr(l10, orc.f64p), threads)
+    return raw, l10, resc
+
+
+@pytest.mark.parametrize("path", PHMM, ids=[os.path.basename(p)[:-4] for p in PHMM])
+def test_golden_strict_bit_exact(ctx, path):
+    g = np.load(path)
+    n = int(g["n_reads"]) * int(g["n_haps"])
+    raw, l10, cnt = ctx.phmm_region(g["reads_ser"].tobytes(), g["haps_ser"].tobytes(), n, A.ACCG_PHMM_STRICT)
+    assert raw.tobytes() == g["raw_scalar_nofma"].tobytes()
+    assert l10.tobytes() == g["log10_scalar_nofma"].tobytes()
+    assert cnt.rescued == int(g["rescued_scalar_nofma"]) and cnt.pairs == n
+
+
+@pytest.mark.parametrize("path", PHMM, ids=[os.path.basename(p)[:-4] for p in PHMM])
+def test_golden_fast_within_tolerance(ctx, path):
+    g = np.load(path)
+    n = int(g["n_reads"]) * int(g["n_haps"])
+    raw, l10, cnt = ctx.phmm_region(g["reads_ser"].tobytes(), g["haps_ser"].tobytes(), n, A.ACCG_PHMM_FAST)
+    want = g["log10_avx"]                       # FalconPairHMM::computePairhmmAVX as the reference builds it
+    assert np.all(np.isfinite(l10))
+    assert (np.abs(l10 - want) / np.abs(want)).max() < REL_TOL
+    ok = g["raw_avx"] > 1e-27                   # away from the rescue threshold the raw fp32 value is judged too
+    assert (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < REL_TOL
+
+
+def test_fast_matches_its_arithmetic_model(ctx):
+    """The fast mode is bit-exact with oracle's FMA restatement: any difference is a kernel bug, not rounding."""
+    O = orc.oracle()
+    rng = synth.rng_for(300)
+    reads, haps = synth.make_region(rng, 9, 5, (20, 120), (30, 200), n_frac=0.02, unrelated_frac=0.2)
+    raw, _, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 45, A.ACCG_PHMM_FAST, want_log10=False)
+    k = 0
+    for r in reads:
+        for h in haps:
+            assert np.float32(O.orc_phmm_forward_f32_fma(*orc.pair_args(r, h))).tobytes() == raw[k].tobytes(), k
+            k += 1
+
+
+@pytest.mark.parametrize("rlen", [1, 2, 15, 16, 17, 31, 32, 47, 48, 63, 64, 79, 80, 95, 96, 111, 112, 127, 128, 143, 144,
+                                  159, 160, 175, 176, 191, 192, 207, 208, 223, 224, 239, 240, 254, 255])
+def test_every_row_count_strict(ctx, rlen):
+    """Every K class (rows per lane) and both sides of each K boundary, ragged haplotype lengths."""
+    rng = synth.rng_for(1000 + rlen)
+    reads, haps = synth.make_region(rng, 5, 7, (max(1, rlen - 3), rlen), (1, 90), n_frac=0.02, unrelated_frac=0.2)
+    reads[0] = synth.make_read(rng, np.frombuffer(haps[0], np.uint8), rlen)
+    raw, l10, cnt = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 35, A.ACCG_PHMM_STRICT)
+    oraw, ol10, oresc = _oracle_region(reads, haps)
+    assert raw.tobytes() == oraw.tobytes()
+    assert l10.tobytes() == ol10.tobytes()
+    assert cnt.rescued == oresc
+
+
+def test_multi_region_batch_and_f64(ctx):
+    rng = synth.rng_for(301)
+    regs = [synth.make_region(rng, int(rng.integers(1, 40)), int(rng.integers(1, 12)), (10, 151), (20, 400),
+                              n_frac=0.01, unrelated_frac=0.3) for _ in range(12)]
+    with A.PhmmBatch(ctx, [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]) as b:
+        assert b.pairs == sum(len(r) * len(h) for r, h in regs)
+        assert b.cells == sum(sum(len(x["b"]) for x in r) * sum(len(y) for y in h) for r, h in regs)
+        b.run(A.ACCG_PHMM_STRICT)
+        raw, l10, cnt = b.results()
+        f64 = b.run_f64()
+    O = orc.oracle()
+    off, resc = 0, 0
+    for reads, haps in regs:
+        oraw, ol10, r = _oracle_region(reads, haps)
+        n = len(reads) * len(haps)
+        assert raw[off:off + n].tobytes() == oraw.tobytes()
+        assert l10[off:off + n].tobytes() == ol10.tobytes()
+        k = off
+        for rd in reads[:3]:
+            for h in haps[:3]:
+                pass
+        # fp64 over every pair is bit-exact with the reference's double baseline
+        want = np.array([O.orc_phmm_forward_f64(*orc.pair_args(rd, h), 0) for rd in reads for h in haps])
+        assert f64[off:off + n].tobytes() == want.tobytes()
+        off += n; resc += r
+    assert cnt.rescued == resc and resc > 0
+
+
+def test_long_haplotypes_and_many_haps(ctx):
+    """Haplotype runs that must be cut into several LDS streams, and a stream of one long haplotype."""
+    rng = synth.rng_for(302)
+    reads, haps = synth.make_region(rng, 6, 70, (90, 110), (200, 380))
+    haps[3] = synth.random_bases(rng, 3999).tobytes()
+    raw, l10, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 6 * 70, A.ACCG_PHMM_STRICT)
+    oraw, ol10, _ = _oracle_region(reads, haps)
+    assert raw.tobytes() == oraw.tobytes() and l10.tobytes() == ol10.tobytes()
+
+
+def test_full_size_c1_properties(ctx):
+    """BASELINE configs[1] at full size (2048 reads x 32 haps of 300): a sampled oracle check plus
+    size-independent properties: permutation invariance over reads/haps and idempotence of reruns."""
+    rng = synth.rng_for(1)
+    reads, haps = synth.make_region(rng, 2048, 32, 101, 300)
+    rs, hs = synth.serialize_reads(reads), synth.serialize_haps(haps)
+    with A.PhmmBatch(ctx, [(rs, hs)]) as b:
+        assert b.pairs == 65536 and b.cells == 2048 * 101 * 32 * 300
+        b.run(A.ACCG_PHMM_FAST)
+        raw1, l1, c1 = b.results()
+        b.run(A.ACCG_PHMM_FAST)
+        raw2, _, _ = b.results()
+    assert raw1.tobytes() == raw2.tobytes()
+    pr, ph = rng.permutation(2048), rng.permutation(32)
+    raw3, _, _ = ctx.phmm_region(synth.serialize_reads([reads[i] for i in pr]), synth.serialize_haps([haps[j] for j in ph]),
+                                 65536, A.ACCG_PHMM_FAST, want_log10=False)
+    assert np.array_equal(raw3.reshape(2048, 32), raw1.reshape(2048, 32)[pr][:, ph])
+    O = orc.oracle()
+    for k in rng.choice(65536, 300, replace=False):
+        r, h = reads[k // 32], haps[k % 32]
+        f = O.orc_phmm_forward_f32(*orc.pair_args(r, h), 0)
+        want = O.orc_phmm_finish(f, *orc.pair_args(r, h), None)
+        assert abs(l1[k] - want) / abs(want) < REL_TOL
+
+
+def test_error_paths(ctx):
+    ok_r = synth.serialize_reads([dict(b=b"ACGT", q=b"\x1e" * 4, i=b"\x28" * 4, d=b"\x28" * 4, c=b"\x0a" * 4)])
+    ok_h = synth.serialize_haps([b"ACGTACGT"])
+    raw, l10, _ = ctx.phmm_region(ok_r, ok_h, 1)
+    assert np.isfinite(l10[0])
+    for bad_r, bad_h, status in (
+            (ok_r[:-3], ok_h, -4), (ok_r, ok_h[:-1], -4),
+            (synth.serialize_reads([dict(b=b"ACXT", q=b"\x1e" * 4, i=b"\x28" * 4, d=b"\x28" * 4, c=b"\x0a" * 4)]), ok_h, -5),
+            (ok_r, synth.serialize_haps([b"acgt"]), -5),
+            (ok_r, synth.serialize_haps([b""]), -6),
+            (synth.serialize_reads([dict(b=b"A" * 256, q=b"\x1e" * 256, i=b"\x28" * 256, d=b"\x28" * 256, c=b"\x0a" * 256)]), ok_h, -7),
+            (ok_r, synth.serialize_haps([b"A" * 4001]), -7)):
+        with pytest.raises(A.AccgError) as e:
+            ctx.phmm_region(bad_r, bad_h, 1)
+        assert e.value.status == status
+    # empty region is fine and yields nothing
+    raw, l10, cnt = ctx.phmm_region(synth.serialize_reads([]), ok_h, 0)
+    assert cnt.pairs == 0
