@@ -31,6 +31,18 @@ def make_c1(rank):
     return reads, haps
 
 
+def host_cores():
+    """CPUs this process may really use: the cgroup quota when there is one (16 on a one-GPU box), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_phmm(reads, haps, min_wall=1.0):
     """The reference's own AVX path (compute_fp_avxs + fp64 rescue + log10, FalconPairHMM.cpp:69-95), compiled
     in place into oracle/_ref, on all host cores: the pair loop is split over threads by read."""
@@ -38,8 +50,7 @@ def cpu_baseline_phmm(reads, haps, min_wall=1.0):
     if not orc.ref_available():
         return None
     R = orc.ref_phmm()
-    cores = len(os.sched_getaffinity(0))
-    n_threads = cores
+    n_threads = host_cores()
     slices = np.array_split(np.arange(len(reads)), n_threads)
     hl = np.array([len(h) for h in haps], np.int32)
     hk = orc.cstrs(list(haps))
