@@ -3,6 +3,7 @@
 // prepare()/compute() (pairhmm/task/xlnx/PairHMMTask.cpp:27-143) and the pair loop + post-process of
 // FalconPairHMM::computePairhmmAVX (pairhmm/xlnx/host/FalconPairHMM.cpp:69-95).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -101,7 +102,7 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K; uint32_t work0, n_work; };
+struct KLaunch { int K; uint32_t work0, n_work; int stream_cap; };
 
 template <typename T>
 struct DevBuf {
@@ -188,8 +189,14 @@ inline int k_for(uint32_t read_len) { return (int)((read_len + 1 + 15) / 16); } 
 // Cuts every region into jobs = (four reads of similar length) x (a run of haplotypes).
 void partition(accg_phmm_batch& b) {
   // how many wavefronts we would like in flight: enough for ~4 per SIMD on every CU
-  const uint64_t target_jobs = (uint64_t)std::max(b.ctx->n_cu, 1) * 4 * 4;
-  struct Job { PhmmWork w; int K; uint64_t cost; };
+  // Many short jobs: single-wave workgroups are placed by the hardware dispatcher, and with only a
+  // few long jobs per SIMD its placement (and the tail) costs up to 30 % (gpurun_out sweep);
+  // ~64 jobs per CU of >= 256 steps each measured best on configs[1].
+  uint64_t target_jobs = (uint64_t)std::max(b.ctx->n_cu, 1) * 64;
+  uint64_t min_steps = 256;   // below this the 15-step fill and the prologue start to show
+  if (const char* e = getenv("ACCG_PHMM_TARGET_JOBS")) target_jobs = strtoull(e, nullptr, 10);   // tuning knobs
+  if (const char* e = getenv("ACCG_PHMM_MIN_STEPS")) min_steps = strtoull(e, nullptr, 10);
+  struct Job { PhmmWork w; int K; uint64_t cost; int stream_len; };
   std::vector<Job> jobs;
   uint64_t total_quads = 0;
   for (const Region& r : b.regions) total_quads += (r.n_reads + 3) / 4;
@@ -204,7 +211,6 @@ void partition(accg_phmm_batch& b) {
     uint64_t stream_total = 0;
     for (uint32_t h = 0; h < r.n_haps; h++) stream_total += b.hp[r.hap0 + h].len + 1;
     uint64_t want_chunks = (target_jobs + total_quads - 1) / std::max<uint64_t>(total_quads, 1);
-    uint64_t min_steps = 512;   // below this the 15-step fill and the prologue start to show
     uint64_t max_chunks_by_len = std::max<uint64_t>(1, stream_total / min_steps);
     want_chunks = std::min<uint64_t>(std::min<uint64_t>(want_chunks, max_chunks_by_len), r.n_haps);
     uint64_t budget = std::max<uint64_t>((stream_total + want_chunks - 1) / std::max<uint64_t>(want_chunks, 1), 1);
@@ -235,7 +241,7 @@ void partition(accg_phmm_batch& b) {
       w.pad_[0] = w.pad_[1] = 0;
       for (const Chunk& c : chunks) {
         w.hap_off = c.ids0; w.n_haps = c.n;
-        jobs.push_back({w, k_for(maxlen), c.steps * (uint64_t)k_for(maxlen)});
+        jobs.push_back({w, k_for(maxlen), c.steps * (uint64_t)k_for(maxlen), (int)(c.steps - 15)});
       }
     }
   }
@@ -244,8 +250,9 @@ void partition(accg_phmm_batch& b) {
   b.work.resize(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     b.work[i] = jobs[i].w;
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K) b.launches.push_back({jobs[i].K, (uint32_t)i, 0});
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K) b.launches.push_back({jobs[i].K, (uint32_t)i, 0, 0});
     b.launches.back().n_work++;
+    b.launches.back().stream_cap = std::max(b.launches.back().stream_cap, (jobs[i].stream_len + 63) / 64 * 64);
   }
 }
 
@@ -260,13 +267,13 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
 
 int launch_f32(accg_phmm_batch* b, int mode) {
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
-  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f32(l.K, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, b->ctx->stream));
+  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f32(l.K, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, l.stream_cap, b->ctx->stream));
   return ACCG_OK;
 }
 int launch_rescue(accg_phmm_batch* b) {
   ACCG_HIP(hipMemsetAsync(b->d_nresc.p, 0, sizeof(unsigned long long), b->ctx->stream));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
-  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_rescue_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_rescue_f64(l.K, a, l.work0, l.n_work, l.stream_cap, b->ctx->stream));
   return ACCG_OK;
 }
 
@@ -355,7 +362,7 @@ extern "C" int accg_phmm_batch_run_f64(accg_phmm_batch* b) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
-  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f64(l.K, a, l.work0, l.n_work, l.stream_cap, b->ctx->stream));
   return ACCG_OK;
 }
 extern "C" int accg_phmm_batch_results_f64(accg_phmm_batch* b, double* out_raw64) {

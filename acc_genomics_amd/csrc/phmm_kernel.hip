@@ -5,41 +5,38 @@
 // read (rows r = 1..R) against one haplotype (columns c = 1..H)
 //     M[r][c] = dist(r,c) * ((M[r-1][c-1]*pMM[r] + X[r-1][c-1]*pGM[r]) + Y[r-1][c-1]*pGM[r])
 //     X[r][c] = M[r-1][c]*pMX[r] + X[r-1][c]*pXX[r]
-//     Y[r][c] = M[r][c-1]*pMY[r] + Y[r][c-1]*pYY[r]
+//     Y[r][c] = M[r][c-1]*pMY[r] + Y[r][c-1]*pYY[r]          (pYY[r] == pXX[r], baseline_impl.cpp:56,58)
 //     result  = sum_c (M[R][c] + X[R][c]),   Y[0][c] = INIT/H, everything else on the border 0.
 //
-// How it is mapped (this is a design of its own, not the FPGA PE array nor the AVX stripes):
+// How it is mapped (a design of its own, neither the FPGA PE array nor the AVX stripes):
 //   * one wavefront = four reads; read g lives in DPP row g (16 lanes); lane l of the row owns K
 //     consecutive read rows in registers (K = ceil((R+1)/16) is a template parameter, so all row
-//     state is register-resident and indexable at compile time).  Rows are right-aligned: the
-//     last read row is always (lane 15, k = K-1); the rows in front are "row 0" clones
-//     (M = X = 0, Y = INIT/H) which makes the top border fall out of the same recurrence.
+//     state is register-resident and indexed at compile time).  Rows are right-aligned: the last
+//     read row is always (lane 15, k = K-1); the rows in front are clones of "row 0"
+//     (M = X = 0, Y = INIT/H), which makes the top border fall out of the same recurrence.
 //   * the four reads sweep the SAME haplotype stream, one column per step, skewed one column per
 //     lane (lane l is at column t-l), so the inter-lane hand-off is exactly one DPP row_shr:1 of
 //     two values per step (the pre-multiplied diagonal term and the X of the row below) - no LDS,
 //     no bpermute.  Inside a lane the K rows are chained through registers.
 //   * all haplotypes of the job are concatenated into one stream in LDS (one "bubble" entry in
 //     front of each haplotype plays column 0), so the 15-step pipeline fill/drain is paid once per
-//     job, not once per pair.  Stream entries are fp16 bit patterns whose *class* encodes the base,
-//     so "read base matches hap base (or either is N)" is a single v_cmp_class_f16 against a per-row
-//     class mask.
+//     job, not once per pair.
+//   * the emission probability dist(r,c) takes one of two per-row values depending on the hap base.
+//     v_cmp/v_cndmask run at about 0.6x the rate of fp32 mul/fma on gfx950 (tools/ubench.hip), so the
+//     selection is done by the LDS instead: a per-wave table T[base][row quad][lane] of 16-byte
+//     vectors holds dist for every (hap base, row); a stream entry is the byte offset of its base's
+//     slab, and one ds_read_b128 per 4 rows (2 rows in fp64) fetches the step's values, conflict-free
+//     (slabs are multiples of 1 KiB apart, so the bank is decided by the lane alone).  Both LDS reads
+//     are software-pipelined one step ahead of their use.
 //   * no MFMA: the recurrence is a chain of fp32 mul/fma along the anti-diagonal, not a contraction.
 #include "phmm_dev.h"
 
 namespace accg {
 namespace {
 
-// fp16 patterns by class.  A:+0  C:-0  G:+inf  T:-inf  N:qNaN  bubble/padding:+1.0 (matches nothing)
-constexpr uint16_t H_A = 0x0000, H_C = 0x8000, H_G = 0x7C00, H_T = 0xFC00, H_N = 0x7E00, H_PAD = 0x3C00;
-// v_cmp_class bit numbers: 1 qNaN, 2 -inf, 5 -0, 6 +0, 9 +inf
-constexpr int C_N = 1 << 1, C_A = (1 << 6) | C_N, C_C = (1 << 5) | C_N, C_G = (1 << 9) | C_N, C_T = (1 << 2) | C_N;
-constexpr int C_ANY = C_A | C_C | C_G | C_T;
-
-__device__ __forceinline__ uint16_t hap_code(uint8_t b) {
-  return b == 'A' ? H_A : b == 'C' ? H_C : b == 'G' ? H_G : b == 'T' ? H_T : b == 'N' ? H_N : H_PAD;
-}
-__device__ __forceinline__ int read_class(uint8_t b) {
-  return b == 'A' ? C_A : b == 'C' ? C_C : b == 'G' ? C_G : b == 'T' ? C_T : b == 'N' ? C_ANY : 0;
+enum { CH_A = 0, CH_C = 1, CH_G = 2, CH_T = 3, CH_N = 4 };
+__device__ __forceinline__ int char_index(uint8_t b) {   // bases are validated on the host (ACCG_ERR_BAD_BASE)
+  return b == 'A' ? CH_A : b == 'C' ? CH_C : b == 'G' ? CH_G : b == 'T' ? CH_T : CH_N;
 }
 
 // lane l <- lane l-1 inside each row of 16; lane 0 of a row receives 0.
@@ -68,20 +65,37 @@ __device__ __forceinline__ T mul_add2(T a, T b, T c, T d) {      // a*b + c*d
   return fma_(a, b, c * d);
 }
 
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); enum { N = 4 }; };
+template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); enum { N = 2 }; };
+
 template <typename T, int K>
 struct Rows {
   T M[K], X[K], Y[K];
-  T pMM[K], pGM[K], pMX[K], pXX[K], pMY[K], dM[K], dX[K];   // pYY == pXX (baseline_impl.cpp:56,58)
-  int cls[K];
-  T nMM, nGM, nMX, nXX;   // row-0 coefficients of the lane to the right
+  T pMM[K], pGM[K], pMX[K], pXX[K], pMY[K];
+  T nMM, nGM, nMX, nXX;   // row-0 coefficients of the lane to the right (lane 15: nMX = nXX = 1, so x_out = M + X)
   T a_out, x_out;         // what this lane hands to the right at the next step
-  T acc;                  // running sum of M+X of the last local row (meaningful in lane 15)
-  unsigned padmask;       // bit k set: local row k is a "row 0" clone
+  T acc;                  // running sum of M+X of the last read row (meaningful in lane 15)
+  unsigned padmask;       // bit k set: local row k is a clone of row 0
 };
 
-// One column for every lane.  h = stream entry of this lane's column.
+// dist values of one step for this lane's K rows: QT vector reads, slab offset `off` (bytes).
+template <typename T, int K>
+__device__ __forceinline__ void load_dist(const unsigned char* tab_lane, unsigned off, T (&d)[K]) {
+  typedef typename Vec16<T>::type V;
+  constexpr int N = Vec16<T>::N, QT = (K + N - 1) / N;
+#pragma unroll
+  for (int q = 0; q < QT; q++) {
+    V v = *reinterpret_cast<const V*>(tab_lane + off + q * 1024);
+#pragma unroll
+    for (int e = 0; e < N; e++)
+      if (q * N + e < K) d[q * N + e] = v[e];
+  }
+}
+
+// One column for every lane.  d[k] = dist of local row k against this lane's column.
 template <bool STRICT, bool BOUNDARY, typename T, int K>
-__device__ __forceinline__ void column(Rows<T, K>& s, _Float16 h, bool rst, T y0) {
+__device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K], bool rst, T y0) {
   T a_in = row_shr1(s.a_out);
   T x_in = row_shr1(s.x_out);
   // pass 1: everything that reads the previous column's state
@@ -90,9 +104,7 @@ __device__ __forceinline__ void column(Rows<T, K>& s, _Float16 h, bool rst, T y0
 #pragma unroll
   for (int k = K - 1; k >= 0; k--) {
     T a = (k == 0) ? a_in : diag_term<STRICT>(s.M[k - 1], s.X[k - 1], s.Y[k - 1], s.pMM[k], s.pGM[k]);
-    bool match = __builtin_amdgcn_classh(h, s.cls[k]);
-    T dist = match ? s.dM[k] : s.dX[k];
-    Mn[k] = dist * a;
+    Mn[k] = d[k] * a;
     Yn[k] = mul_add2<STRICT>(s.M[k], s.pMY[k], s.Y[k], s.pXX[k]);
     if (BOUNDARY) {   // this lane sits on a bubble: column 0 of a new haplotype
       Mn[k] = rst ? T(0) : Mn[k];
@@ -100,46 +112,50 @@ __device__ __forceinline__ void column(Rows<T, K>& s, _Float16 h, bool rst, T y0
     }
   }
   // pass 2: the X chain runs down the rows of the *current* column
-  T xprev = x_in;
+  T xk = x_in;
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    T xn = (k == 0) ? x_in : mul_add2<STRICT>(Mn[k - 1], s.pMX[k], xprev, s.pXX[k]);
-    s.M[k == 0 ? 0 : k - 1] = (k == 0) ? s.M[0] : Mn[k - 1];   // retire row k-1's M once consumed
-    if (k > 0) s.X[k - 1] = xprev;
-    xprev = xn;
+    if (k > 0) xk = mul_add2<STRICT>(Mn[k - 1], s.pMX[k], xk, s.pXX[k]);
+    s.X[k] = xk;
   }
-  s.X[K - 1] = xprev;
-  s.M[K - 1] = Mn[K - 1];
 #pragma unroll
-  for (int k = 0; k < K; k++) s.Y[k] = Yn[k];
+  for (int k = 0; k < K; k++) { s.M[k] = Mn[k]; s.Y[k] = Yn[k]; }
   s.x_out = mul_add2<STRICT>(s.M[K - 1], s.nMX, s.X[K - 1], s.nXX);
-  s.acc = s.acc + (s.M[K - 1] + s.X[K - 1]);
+  s.acc = s.acc + s.x_out;   // lane 15: x_out == M + X of the last read row (baseline_impl.cpp:91)
 }
 
 template <typename T, int K, bool STRICT, bool RESCUE>
-__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
-  __shared__ uint16_t stream[PHMM_STREAM_MAX + 48];
-  __shared__ T y0s[PHMM_HAPS_MAX + 1];
-  __shared__ uint32_t hcol[PHMM_HAPS_MAX + 1];
-  __shared__ uint32_t bpos[PHMM_HAPS_MAX + 2];
+__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, int stream_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
+  constexpr unsigned SLAB = QT * 1024;                 // bytes between two bases' tables
+  unsigned char* tab = smem;
+  uint16_t* stream = reinterpret_cast<uint16_t*>(smem + PHMM_NCHAR * SLAB);
+  T* y0s = reinterpret_cast<T*>(smem + PHMM_NCHAR * SLAB + (((size_t)(15 + stream_cap + 48) * 2 + 15) / 16) * 16);
+  uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + ((sizeof(T) * (PHMM_HAPS_MAX + 1) + 15) / 16) * 16);
+  uint32_t* bpos = hcol + PHMM_HAPS_MAX + 1;
 
   const int lane = threadIdx.x;
   const int g = lane >> 4, l = lane & 15;
-  const PhmmWork w = a.work[work_base + blockIdx.x];
-  const int n_list = __builtin_amdgcn_readfirstlane((int)w.n_haps);
+  // (field-wise loads: indexing a by-value copy of the struct with g would put it in scratch)
+  const PhmmWork* wp = a.work + (work_base + blockIdx.x);
+  const int n_list = __builtin_amdgcn_readfirstlane((int)wp->n_haps);
+  const uint32_t hap_off = __builtin_amdgcn_readfirstlane(wp->hap_off);
 
-  const uint32_t ridx = w.read[g];
+  const uint32_t ridx = wp->read[g];
   const bool have = ridx != PHMM_NO_READ;
   SeqRef rr = {0u, 0u};
   uint32_t out_base = 0;
   if (have) { rr = a.rd[ridx]; out_base = a.rd_out[ridx]; }
 
   // ---- haplotype stream: [15 pad] bubble hap0 bubble hap1 ... bubble(terminal) [pad] ----------
+  // an entry is the byte offset of its base's slab in the dist table; bubbles/padding use slab 0
+  // (their dist value is never kept: M is forced to 0 on a bubble, and all state is 0 in the padding)
   int pos = 0, n_haps = 0;
   unsigned n_flag = 0;
-  for (int i = lane; i < 15; i += 64) stream[i] = H_PAD;
+  for (int i = lane; i < 15; i += 64) stream[i] = 0;
   for (int j = 0; j < n_list; j++) {
-    const uint32_t gh = a.hap_ids[w.hap_off + j];
+    const uint32_t gh = a.hap_ids[hap_off + j];
     const uint32_t col = a.hp_local[gh];
     if (RESCUE) {   // keep this haplotype only if one of the four reads underflowed in fp32 against it
       const bool under = have && l == 0 && a.raw[out_base + col] < PHMM_MIN_ACCEPTED;
@@ -149,12 +165,12 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     }
     const SeqRef hr = a.hp[gh];
     if (lane == 0) {
-      stream[15 + pos] = H_PAD;
+      stream[15 + pos] = 0;
       bpos[n_haps] = pos;
       y0s[n_haps] = a.tab.init / (T)(int)hr.len;     // baseline_impl.cpp:63
       hcol[n_haps] = col;
     }
-    for (int i = lane; i < (int)hr.len; i += 64) stream[15 + pos + 1 + i] = hap_code(a.hblob[hr.off + i]);
+    for (int i = lane; i < (int)hr.len; i += 64) stream[15 + pos + 1 + i] = (uint16_t)(char_index(a.hblob[hr.off + i]) * SLAB);
     pos += (int)hr.len + 1;
     n_haps++;
   }
@@ -163,35 +179,53 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     if (lane == 0) atomicAdd(a.n_rescued, (unsigned long long)n_flag);
   }
   if (lane == 0) { bpos[n_haps] = pos; bpos[n_haps + 1] = 0x7FFFFFFF; y0s[n_haps] = T(0); hcol[n_haps] = 0; }
-  for (int i = lane; i < 33; i += 64) stream[15 + pos + i] = H_PAD;   // terminal bubble + drain
+  for (int i = lane; i < 36; i += 64) stream[15 + pos + i] = 0;       // terminal bubble + drain + prefetch slack
   const int t_end = __builtin_amdgcn_readfirstlane(pos + 16);          // lane 15 passes the terminal bubble at pos+15
 
-  // ---- per-row constants (registers) ------------------------------------------------------------
+  // ---- per-row constants (registers) and the dist table (LDS) ---------------------------------
   Rows<T, K> s;
   const int R = (int)rr.len;
   const int pad = 16 * K - R;               // >= 1 by construction of the job
   const uint8_t* rb = a.rblob + rr.off;
   s.padmask = 0;
+  typedef typename Vec16<T>::type V;
 #pragma unroll
-  for (int k = 0; k < K; k++) {
-    const int r = l * K + k - pad;          // 0-based read row, < 0: clone of row 0
-    s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = T(0);
-    if (r >= 0) {
-      const int qq = rb[R + r] & 127, qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
-      const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
-      s.pMM[k] = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];   // Context.h:163-174
-      s.pGM[k] = a.tab.omph[qc];                            // baseline_impl.cpp:54
-      s.pMX[k] = a.tab.ph[qi];
-      s.pXX[k] = a.tab.ph[qc];
-      s.pMY[k] = a.tab.ph[qd];
-      s.dM[k] = a.tab.omph[qq];                             // baseline_impl.cpp:79-81
-      s.dX[k] = a.tab.phd3[qq];                             // baseline_impl.cpp:83
-      s.cls[k] = read_class(rb[r]);
-    } else {
-      // clone of row 0: M stays 0 (dist = 0), X stays 0 (0*0 + 0*1), Y keeps INIT/H (0*0 + Y*1)
-      s.pMM[k] = T(0); s.pGM[k] = T(0); s.pMX[k] = T(0); s.pXX[k] = T(1); s.pMY[k] = T(0);
-      s.dM[k] = T(0); s.dX[k] = T(0); s.cls[k] = 0;
-      s.padmask |= 1u << k;
+  for (int q = 0; q < QT; q++) {
+    T dM[VN], dX[VN];
+    int rbase[VN];
+#pragma unroll
+    for (int e = 0; e < VN; e++) {
+      const int k = q * VN + e;
+      dM[e] = T(0); dX[e] = T(0); rbase[e] = CH_A;
+      if (k < K) {
+        const int r = l * K + k - pad;          // 0-based read row, < 0: clone of row 0
+        s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = T(0);
+        if (r >= 0) {
+          const int qq = rb[R + r] & 127, qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
+          const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
+          s.pMM[k] = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];   // Context.h:163-174
+          s.pGM[k] = a.tab.omph[qc];                            // baseline_impl.cpp:54
+          s.pMX[k] = a.tab.ph[qi];
+          s.pXX[k] = a.tab.ph[qc];
+          s.pMY[k] = a.tab.ph[qd];
+          dM[e] = a.tab.omph[qq];                               // baseline_impl.cpp:79-81
+          dX[e] = a.tab.phd3[qq];                               // baseline_impl.cpp:83
+          rbase[e] = char_index(rb[r]);
+        } else {
+          // clone of row 0: M stays 0 (dist = 0), X stays 0 (0*0 + 0*1), Y keeps INIT/H (0*0 + Y*1)
+          s.pMM[k] = T(0); s.pGM[k] = T(0); s.pMX[k] = T(0); s.pXX[k] = T(1); s.pMY[k] = T(0);
+          s.padmask |= 1u << k;
+        }
+      }
+    }
+    // dist table: one 16-byte vector per (hap base, row quad, lane)
+#pragma unroll
+    for (int c = 0; c < PHMM_NCHAR; c++) {
+      V v;
+#pragma unroll
+      for (int e = 0; e < VN; e++)   // rs == hap || rs == 'N' || hap == 'N'   (baseline_impl.cpp:80)
+        v[e] = (c == CH_N || rbase[e] == CH_N || rbase[e] == c) ? dM[e] : dX[e];
+      *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
     }
   }
   {
@@ -203,21 +237,33 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       s.nGM = a.tab.omph[qc];
       s.nMX = a.tab.ph[qi];
       s.nXX = a.tab.ph[qc];
-    } else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
+    } else if (l == 15) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
+    else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
   __syncthreads();
 
   // ---- sweep ----------------------------------------------------------------------------------
-  const _Float16* hs = reinterpret_cast<const _Float16*>(stream) + 15 - l;   // hs[t] = this lane's column at step t
+  const uint16_t* hs = stream + 15 - l;               // hs[t] = this lane's column at step t
+  const unsigned char* tab_lane = tab + lane * 16;
   int t = 0, jn = 0, jl = -1;
   int nb = 0;                 // stream position of the next bubble lane 0 will meet
   unsigned rm = 0;            // bit i: lane i of every row is on a bubble this step
+  T dn[K];                    // dist of step t   (loaded one step ahead)
+  load_dist<T, K>(tab_lane, hs[0], dn);
+  unsigned o1 = hs[1];        // slab offset of step t+1 (loaded two steps ahead)
   constexpr int U = 4;
   while (t < t_end) {
     if (rm == 0 && nb - t >= U) {
 #pragma unroll
-      for (int u = 0; u < U; u++) column<STRICT, false>(s, hs[t + u], false, T(0));
+      for (int u = 0; u < U; u++) {
+        T d[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) d[k] = dn[k];
+        load_dist<T, K>(tab_lane, o1, dn);
+        o1 = hs[t + u + 2];
+        column<STRICT, false>(s, d, false, T(0));
+      }
       t += U;
       continue;
     }
@@ -232,16 +278,25 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       y0 = y0s[jl];
       s.acc = T(0);
     }
-    column<STRICT, true>(s, hs[t], rst, y0);
+    T d[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) d[k] = dn[k];
+    load_dist<T, K>(tab_lane, o1, dn);
+    o1 = hs[t + 2];
+    column<STRICT, true>(s, d, rst, y0);
     t++;
   }
 }
 
 template <typename T, bool STRICT, bool RESCUE>
-hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
+hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, int stream_cap, hipStream_t st) {
   if (n_work == 0) return hipSuccess;
   dim3 grid(n_work), block(64);
-#define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((phmm_kernel<T, KK, STRICT, RESCUE>), grid, block, 0, st, a, work_base); break;
+#define ACCG_CASE(KK)                                                                                         \
+  case KK: {                                                                                                  \
+    const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), stream_cap);                                        \
+    hipLaunchKernelGGL((phmm_kernel<T, KK, STRICT, RESCUE>), grid, block, lds, st, a, work_base, stream_cap); \
+  } break;
   switch (K) {
     ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
     ACCG_CASE(9) ACCG_CASE(10) ACCG_CASE(11) ACCG_CASE(12) ACCG_CASE(13) ACCG_CASE(14) ACCG_CASE(15) ACCG_CASE(16)
@@ -253,14 +308,14 @@ hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_wo
 
 }  // namespace
 
-hipError_t phmm_launch_f32(int K, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return strict ? launch<float, true, false>(K, a, wb, n, s) : launch<float, false, false>(K, a, wb, n, s);
+hipError_t phmm_launch_f32(int K, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
+  return strict ? launch<float, true, false>(K, a, wb, n, cap, s) : launch<float, false, false>(K, a, wb, n, cap, s);
 }
-hipError_t phmm_launch_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, false>(K, a, wb, n, s);
+hipError_t phmm_launch_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
+  return launch<double, true, false>(K, a, wb, n, cap, s);
 }
-hipError_t phmm_launch_rescue_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, true>(K, a, wb, n, s);
+hipError_t phmm_launch_rescue_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
+  return launch<double, true, true>(K, a, wb, n, cap, s);
 }
 
 }  // namespace accg
