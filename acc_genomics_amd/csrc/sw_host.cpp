@@ -1,0 +1,167 @@
+// Host side of the HTC Smith-Waterman path: batch upload, pairing/packing of pairs into wavefront jobs,
+// launches, results.  Stands in for the pair loop of SWPairwiseAlignmentMultiBatch
+// (htc-sw/host/FalconSW_AVX.cpp:304-313) up to and including the end-cell selection (:2314-2339).
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <numeric>
+#include <vector>
+#include "accg_internal.h"
+#include "sw_dev.h"
+
+using namespace accg;
+
+namespace {
+struct SwLaunch { int K; bool pack16, lane_is_alt; uint32_t work0, n_work; int sweep_cap; };
+template <typename T> int dev_upload(T** dst, const void* src, size_t bytes, hipStream_t s) {
+  ACCG_HIP(hipMalloc((void**)dst, bytes ? bytes : 16));
+  if (bytes) ACCG_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
+  return ACCG_OK;
+}
+}  // namespace
+
+struct accg_sw_batch {
+  accg_ctx* ctx = nullptr;
+  int n = 0;
+  uint64_t cells = 0, algo_bytes = 0;
+  std::vector<SwLaunch> launches;
+  uint8_t *d_refs = nullptr, *d_alts = nullptr, *d_strat = nullptr;
+  int32_t *d_rl = nullptr, *d_al = nullptr, *d_score = nullptr, *d_p1 = nullptr, *d_p2 = nullptr;
+  SwWork* d_work = nullptr;
+  SwArgs args{};
+};
+
+extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, size_t ref_stride, const int32_t* ref_lens,
+                                    const uint8_t* alts, size_t alt_stride, const int32_t* alt_lens,
+                                    const uint8_t* strategies, int w_match, int w_mismatch, int w_open, int w_extend,
+                                    accg_sw_batch** out) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out || n < 0 || (n > 0 && (!refs || !alts || !ref_lens || !alt_lens))) return ACCG_ERR_BAD_ARG;
+  *out = nullptr;
+  ACCG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<accg_sw_batch> b(new accg_sw_batch);
+  b->ctx = ctx; b->n = n;
+  struct Item { uint32_t idx; int K, ns; bool p16, lia; };
+  std::vector<Item> items(n);
+  int max_rl = 0, max_al = 0;
+  for (int k = 0; k < n; k++) {
+    const int rl = ref_lens[k], al = alt_lens[k];
+    if (rl <= 0 || al <= 0) return ACCG_ERR_EMPTY_SEQ;
+    if (rl > ACCG_SW_MAX_LEN || al > ACCG_SW_MAX_LEN || std::min(rl, al) > ACCG_SW_MAX_SHORT) return ACCG_ERR_TOO_LONG;
+    if (strategies && strategies[k] > 3) return ACCG_ERR_BAD_ARG;
+    max_rl = std::max(max_rl, rl); max_al = std::max(max_al, al);
+    const bool lia = al <= rl;                       // lanes hold the shorter sequence
+    const int nl = lia ? al : rl, ns = lia ? rl : al;
+    // 16-bit mode only when every reachable matrix value provably fits:
+    // highest: nl matches; lowest: a border prefill of ns gaps plus nl mismatches plus one more open.
+    const long hi = (long)std::max(w_match, 0) * nl;
+    const long lo = (long)std::min(w_open, 0) * 2 + (long)std::min(w_extend, 0) * ns + (long)std::min(w_mismatch, 0) * nl;
+    const bool p16 = hi <= 32000 && lo >= -32000 && std::abs(w_match) < 16000 && std::abs(w_mismatch) < 16000;
+    items[k] = {(uint32_t)k, (nl + 1 + 15) / 16, ns, p16, lia};
+    b->cells += (uint64_t)rl * al;
+    b->algo_bytes += (uint64_t)rl + al + 16;
+  }
+  if ((ref_stride != 0 && (size_t)max_rl > ref_stride) || (alt_stride != 0 && (size_t)max_al > alt_stride)) return ACCG_ERR_BAD_ARG;
+  std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
+    if (x.lia != y.lia) return x.lia > y.lia;
+    if (x.p16 != y.p16) return x.p16 > y.p16;
+    if (x.K != y.K) return x.K > y.K;
+    return x.ns > y.ns;
+  });
+  // groups of one (int32) or two (16-bit, equal sweep length) pairs; four groups per wavefront
+  std::vector<SwWork> work;
+  size_t i = 0;
+  while (i < items.size()) {
+    const Item& first = items[i];
+    SwLaunch L{first.K, first.p16, first.lia, (uint32_t)work.size(), 0, 0};
+    std::vector<std::pair<uint32_t, uint32_t>> groups;
+    while (i < items.size() && items[i].K == first.K && items[i].p16 == first.p16 && items[i].lia == first.lia) {
+      L.sweep_cap = std::max(L.sweep_cap, items[i].ns);
+      if (first.p16 && i + 1 < items.size() && items[i + 1].K == first.K && items[i + 1].p16 && items[i + 1].lia == first.lia &&
+          items[i + 1].ns == items[i].ns) {
+        groups.push_back({items[i].idx, items[i + 1].idx}); i += 2;
+      } else { groups.push_back({items[i].idx, SW_NO_PAIR}); i += 1; }
+    }
+    for (size_t gI = 0; gI < groups.size(); gI += 4) {
+      SwWork w;
+      for (int g = 0; g < 4; g++) {
+        w.pair[2 * g] = gI + g < groups.size() ? groups[gI + g].first : SW_NO_PAIR;
+        w.pair[2 * g + 1] = gI + g < groups.size() ? groups[gI + g].second : SW_NO_PAIR;
+      }
+      work.push_back(w);
+    }
+    L.n_work = (uint32_t)work.size() - L.work0;
+    b->launches.push_back(L);
+  }
+  hipStream_t s = ctx->stream;
+  std::vector<uint8_t> strat(std::max(n, 1), 0);
+  if (strategies) memcpy(strat.data(), strategies, n);
+  const size_t rbytes = ref_stride ? ref_stride * (size_t)n : (size_t)max_rl, abytes = alt_stride ? alt_stride * (size_t)n : (size_t)max_al;
+  int st;
+  if ((st = dev_upload(&b->d_refs, refs, rbytes, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(&b->d_alts, alts, abytes, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(&b->d_rl, ref_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(&b->d_al, alt_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(&b->d_strat, strat.data(), n, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(&b->d_work, work.data(), sizeof(SwWork) * work.size(), s)) != ACCG_OK) return st;
+  ACCG_HIP(hipMalloc((void**)&b->d_score, sizeof(int32_t) * std::max(n, 1)));
+  ACCG_HIP(hipMalloc((void**)&b->d_p1, sizeof(int32_t) * std::max(n, 1)));
+  ACCG_HIP(hipMalloc((void**)&b->d_p2, sizeof(int32_t) * std::max(n, 1)));
+  ACCG_HIP(hipStreamSynchronize(s));
+  SwArgs& a = b->args;
+  a.refs = b->d_refs; a.alts = b->d_alts; a.ref_stride = (uint32_t)ref_stride; a.alt_stride = (uint32_t)alt_stride;
+  a.ref_len = b->d_rl; a.alt_len = b->d_al; a.strategy = b->d_strat; a.work = b->d_work;
+  a.score = b->d_score; a.p1 = b->d_p1; a.p2 = b->d_p2;
+  a.w_match = w_match; a.w_mismatch = w_mismatch; a.w_open = w_open; a.w_extend = w_extend;
+  *out = b.release();
+  return ACCG_OK;
+}
+
+extern "C" uint64_t accg_sw_batch_cells(const accg_sw_batch* b) { return b ? b->cells : 0; }
+extern "C" uint64_t accg_sw_batch_algorithmic_bytes(const accg_sw_batch* b) { return b ? b->algo_bytes : 0; }
+
+extern "C" int accg_sw_batch_run(accg_sw_batch* b) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  for (const SwLaunch& l : b->launches)
+    ACCG_HIP(sw_launch(l.K, l.pack16, l.lane_is_alt, b->args, l.work0, l.n_work, l.sweep_cap, b->ctx->stream));
+  return ACCG_OK;
+}
+
+extern "C" int accg_sw_batch_time(accg_sw_batch* b, int warmup, int iters, float* ms_per_run) {
+  if (!b || !ms_per_run || iters <= 0 || warmup < 0) return ACCG_ERR_BAD_ARG;
+  accg_ctx* c = b->ctx;
+  int st;
+  for (int i = 0; i < warmup; i++) if ((st = accg_sw_batch_run(b)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < iters; i++) if ((st = accg_sw_batch_run(b)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
+  ACCG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_run = ms / iters;
+  return ACCG_OK;
+}
+
+extern "C" int accg_sw_batch_results(accg_sw_batch* b, int32_t* score, int32_t* p1, int32_t* p2) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  const size_t bytes = sizeof(int32_t) * (size_t)b->n;
+  if (bytes) {
+    if (score) ACCG_HIP(hipMemcpy(score, b->d_score, bytes, hipMemcpyDeviceToHost));
+    if (p1) ACCG_HIP(hipMemcpy(p1, b->d_p1, bytes, hipMemcpyDeviceToHost));
+    if (p2) ACCG_HIP(hipMemcpy(p2, b->d_p2, bytes, hipMemcpyDeviceToHost));
+  }
+  return ACCG_OK;
+}
+
+extern "C" void accg_sw_batch_destroy(accg_sw_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  for (void* p : {(void*)b->d_refs, (void*)b->d_alts, (void*)b->d_strat, (void*)b->d_rl, (void*)b->d_al, (void*)b->d_score,
+                  (void*)b->d_p1, (void*)b->d_p2, (void*)b->d_work})
+    if (p) hipFree(p);
+  delete b;
+}

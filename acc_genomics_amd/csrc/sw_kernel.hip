@@ -1,0 +1,271 @@
+// HTC (GATK SWPairwiseAlignment) Smith-Waterman fill + end-cell selection for gfx950, hand-written HIP.
+//
+// What it computes: the matrix of calculateMatrixOneBatch (htc-sw/host/FalconSW_AVX.cpp:1693-1823)
+//     diag = H[i-1][j-1] + (ref[i]==alt[j] ? w_match : w_mismatch)
+//     V[i][j]  = max(V[i-1][j]  + w_extend, H[i-1][j] + w_open)      (best_gap_v[j], :1772-1779)
+//     Hh[i][j] = max(Hh[i][j-1] + w_extend, H[i][j-1] + w_open)      (best_gap_h[i], :1784-1793)
+//     H[i][j]  = max(diag, Hh, V)                                     (:1797-1810; the cutoff -1e8 never binds)
+// with H[0][*] = H[*][0] = 0, or open+(k-1)*extend for the INDEL / LEADING_INDEL strategies (:1732-1746),
+// followed by the end-cell rule of calculateCigarOneBatch (:2314-2339).  Outputs per pair: the score
+// sw[p1][p2] and the cell (p1, p2) -- the quantities BASELINE.json requires bit-exact.
+//
+// Mapping: a pair lives in one DPP row (16 lanes).  One of its two sequences (the "lane sequence",
+// the shorter one) is spread over the lanes, K consecutive positions per lane in registers,
+// right-aligned so that its last position is always (lane 15, k = K-1); the other (the "sweep
+// sequence") is streamed from LDS one position per step, skewed one position per lane, so the only
+// cross-lane traffic is a DPP row_shr:1 of two values per step (H and the lane-direction gap of the
+// lane's last position).  Positions in front of the sequence are border clones that reproduce
+// H[.][0] out of the same recurrence (score 0 / -inf, open = -inf), so there is no border special
+// case in the loop.  In 16-bit mode two pairs share a row in the lo/hi halves of every register
+// (v_pk_add_i16 clamp / v_pk_max_i16), so a wavefront works on 8 pairs.  Lanes are switched off
+// (EXEC) before their first and after their last sweep position, which freezes exactly the values
+// the end-cell rule needs: the registers end up holding H[.][last sweep position], and the last
+// lane's last position is logged to LDS every step.  No MFMA: integer max-plus recurrence.
+#include "sw_dev.h"
+
+namespace accg {
+namespace {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+
+constexpr int NEG16 = -32768;
+constexpr int NEG32 = -1073741824;   // FalconSW_AVX.cpp:1700 lowInitValue
+
+// ---- value abstraction: packed 2 x int16 (saturating) or int32 ------------------------------------
+template <bool P16> struct Val;
+template <> struct Val<true> {
+  typedef s2 T;
+  static __device__ __forceinline__ T splat(int v) { T r = {(short)v, (short)v}; return r; }
+  static __device__ __forceinline__ T make(int lo, int hi) { T r = {(short)lo, (short)hi}; return r; }
+  static __device__ __forceinline__ T adds(T a, T b) { return __builtin_elementwise_add_sat(a, b); }
+  static __device__ __forceinline__ T mx(T a, T b) { return __builtin_elementwise_max(a, b); }
+  static __device__ __forceinline__ T score(T a, T b, T wm, T wd) {   // a == b ? wm : wm + wd, per half
+    u2 one = {1, 1};
+    u2 neq = __builtin_elementwise_min(__builtin_bit_cast(u2, a) ^ __builtin_bit_cast(u2, b), one);
+    return __builtin_bit_cast(T, neq) * wd + wm;
+  }
+  static __device__ __forceinline__ int bits(T a) { return __builtin_bit_cast(int, a); }
+  static __device__ __forceinline__ T from_bits(int b) { return __builtin_bit_cast(T, b); }
+  static __device__ __forceinline__ int get(T a, int half) { return half ? (int)a.y : (int)a.x; }
+  enum { NEG = NEG16 };
+};
+template <> struct Val<false> {
+  typedef int T;
+  static __device__ __forceinline__ T splat(int v) { return v; }
+  static __device__ __forceinline__ T make(int lo, int) { return lo; }
+  static __device__ __forceinline__ T adds(T a, T b) { return a + b; }
+  static __device__ __forceinline__ T mx(T a, T b) { return a > b ? a : b; }
+  static __device__ __forceinline__ T score(T a, T b, T wm, T wd) { return a == b ? wm : wm + wd; }
+  static __device__ __forceinline__ int bits(T a) { return a; }
+  static __device__ __forceinline__ T from_bits(int b) { return b; }
+  static __device__ __forceinline__ int get(T a, int) { return a; }
+  enum { NEG = NEG32 };
+};
+
+template <int OLD>
+__device__ __forceinline__ int row_shr1_old(int v) {   // lane 0 of every row receives OLD
+  return __builtin_amdgcn_update_dpp(OLD, v, 0x111, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ int iabs(int x) { return x < 0 ? -x : x; }
+
+// Candidate ordering of the end-cell rule (FalconSW_AVX.cpp:2320-2337) as one key: higher score wins;
+// then the smaller distance to the main diagonal; then the earlier candidate (the last-column
+// winner comes first, then bottom-row cells in increasing j).
+__device__ __forceinline__ unsigned long long cand_key(int score, int dist, int order) {
+  return ((unsigned long long)(unsigned)(score + 0x40000000) << 24) | ((unsigned long long)(4095 - dist) << 12) |
+         (unsigned long long)(4095 - order);
+}
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {   // max over the 16 lanes of a row
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    unsigned lo = __shfl_xor((unsigned)v, m, 16), hi = __shfl_xor((unsigned)(v >> 32), m, 16);
+    unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int K, bool P16, bool LANE_IS_ALT>
+__global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, int sweep_cap) {
+  typedef Val<P16> VT;
+  typedef typename VT::T T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // per group: sweep characters (two pairs packed lo|hi<<16) and the log of the last lane position
+  uint32_t* sweep_ch = reinterpret_cast<uint32_t*>(smem);                 // [4][sweep_cap + 1]
+  int32_t* edge_log = reinterpret_cast<int32_t*>(smem) + 4 * (sweep_cap + 1);   // [4][sweep_cap + 1] (bits of T)
+
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const SwWork* wp = a.work + (work_base + blockIdx.x);
+  const uint32_t pr[2] = {wp->pair[2 * g], P16 ? wp->pair[2 * g + 1] : SW_NO_PAIR};
+  const bool have[2] = {pr[0] != SW_NO_PAIR, pr[1] != SW_NO_PAIR};
+
+  int nl[2] = {0, 0}, ns = 0, prefill[2] = {0, 0}, strat[2] = {0, 0};
+  const uint8_t* lseq[2] = {nullptr, nullptr};
+  const uint8_t* sseq[2] = {nullptr, nullptr};
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+    if (have[h]) {
+      const int rl = a.ref_len[pr[h]], al = a.alt_len[pr[h]];
+      const uint8_t* rp = a.refs + (size_t)pr[h] * a.ref_stride;
+      const uint8_t* ap = a.alts + (size_t)pr[h] * a.alt_stride;
+      nl[h] = LANE_IS_ALT ? al : rl;
+      ns = LANE_IS_ALT ? rl : al;              // the two halves of a group have the same sweep length (host)
+      lseq[h] = LANE_IS_ALT ? ap : rp;
+      sseq[h] = LANE_IS_ALT ? rp : ap;
+      strat[h] = a.strategy[pr[h]];
+      prefill[h] = (strat[h] == 1 || strat[h] == 2);   // INDEL, LEADING_INDEL: FalconSW_AVX.cpp:1732
+    }
+
+  // ---- sweep characters into LDS -----------------------------------------------------------------
+  uint32_t* my_ch = sweep_ch + g * (sweep_cap + 1);
+  int32_t* my_log = edge_log + g * (sweep_cap + 1);
+  for (int i = l; i < ns; i += 16) {
+    uint32_t c0 = have[0] ? sseq[0][i] : 0u, c1 = have[1] ? sseq[1][i] : 0u;
+    my_ch[i + 1] = c0 | (c1 << 16);
+  }
+
+  // ---- per-position constants ---------------------------------------------------------------------
+  // position p (1-based along the lane sequence) of half h sits at flat index p - 1 + pad_h; flat < pad_h
+  // is a border clone: score 0 (no prefill) or -inf (prefill), lane-direction open = -inf.
+  T ch[K], wm[K], wd[K], opn[K], Hp[K], G[K];
+  const int W_M = a.w_match, W_X = a.w_mismatch, W_O = a.w_open, W_E = a.w_extend;
+  const int NEG = VT::NEG;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int c_[2], wm_[2], wd_[2], op_[2], h_[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int pad = 16 * K - nl[h];
+      const int p = l * K + k - pad + 1;       // 1-based position, <= 0: border clone
+      if (have[h] && p >= 1) {
+        c_[h] = lseq[h][p - 1]; wm_[h] = W_M; wd_[h] = W_X - W_M; op_[h] = W_O;
+        h_[h] = prefill[h] ? W_O + (p - 1) * W_E : 0;                 // H at sweep index 0
+      } else {
+        c_[h] = 0x100;                                                 // never equals a base byte
+        wm_[h] = prefill[h] ? NEG / 2 : 0; wd_[h] = 0; op_[h] = NEG; h_[h] = 0;
+      }
+    }
+    ch[k] = VT::make(c_[0], c_[1]); wm[k] = VT::make(wm_[0], wm_[1]); wd[k] = VT::make(wd_[0], wd_[1]);
+    opn[k] = VT::make(op_[0], op_[1]); Hp[k] = VT::make(h_[0], h_[1]); G[k] = VT::splat(NEG);
+  }
+  const T ext = VT::splat(W_E), opn_s = VT::splat(W_O);
+  T h_in = VT::splat(0), d_in = VT::splat(0), f_in = VT::splat(NEG);
+  T h_last = Hp[K - 1], f_last = VT::splat(NEG);
+  // what the border clone in front of lane 0 hands over: H[i][0] along the sweep
+  // (lane 0, k = 0 is always a clone, so only its *inputs* matter: 0 / NEG below)
+  int t_end = ns + 15;
+#pragma unroll
+  for (int m = 16; m < 64; m <<= 1) { int o = __shfl_xor(t_end, m); t_end = o > t_end ? o : t_end; }
+  t_end = __builtin_amdgcn_readfirstlane(t_end);
+  __syncthreads();
+
+  // ---- sweep ---------------------------------------------------------------------------------------
+  for (int t = 1; t <= t_end; t++) {
+    // hand-off from the lane on the left (all lanes, also the switched-off ones: their registers are frozen)
+    d_in = h_in;
+    h_in = VT::from_bits(row_shr1_old<0>(VT::bits(h_last)));
+    f_in = VT::from_bits(P16 ? row_shr1_old<(int)0x80008000>(VT::bits(f_last)) : row_shr1_old<NEG32>(VT::bits(f_last)));
+    const int i = t - l;                       // this lane's sweep index
+    if (i >= 1 && i <= ns) {
+      const T c = VT::from_bits((int)my_ch[i]);
+      T hup = h_in, hdiag = d_in, f = f_in;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const T hold = Hp[k];
+        f = VT::mx(VT::adds(f, ext), VT::adds(hup, opn[k]));            // gap along the lanes
+        G[k] = VT::mx(VT::adds(G[k], ext), VT::adds(hold, opn_s));      // gap along the sweep
+        const T dg = VT::adds(hdiag, VT::score(ch[k], c, wm[k], wd[k]));
+        const T hn = VT::mx(VT::mx(dg, G[k]), f);
+        hdiag = hold; hup = hn; Hp[k] = hn;
+      }
+      h_last = hup; f_last = f;
+      if (l == 15) my_log[i] = VT::bits(hup);
+    }
+  }
+  __syncthreads();
+
+  // ---- end cell (calculateCigarOneBatch, FalconSW_AVX.cpp:2314-2339) ---------------------------------
+  // "edge" candidates: H[lane-seq end][sweep index s], s = 1..ns (from the log);
+  // "final" candidates: H[lane position p][sweep end], p = 1..nl (in registers).
+  // LANE_IS_ALT: edge = last column (i = s, j = altLen), final = bottom row (i = refLen, j = p); else the converse.
+#pragma unroll
+  for (int h = 0; h < (P16 ? 2 : 1); h++) {
+    if (!have[h]) continue;   // uniform per group of 16 lanes; shuffles below stay inside the group
+    const int refLen = LANE_IS_ALT ? ns : nl[h], altLen = LANE_IS_ALT ? nl[h] : ns;
+    const int pad = 16 * K - nl[h];
+    // last column: ties -> larger i  (:2320-2326)
+    unsigned long long ck = 0;
+    if (LANE_IS_ALT) {
+      for (int s = l + 1; s <= ns; s += 16) {
+        int v = VT::get(VT::from_bits(my_log[s]), h);
+        unsigned long long key = ((unsigned long long)(unsigned)(v + 0x40000000) << 16) | (unsigned)s;
+        ck = key > ck ? key : ck;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int p = l * K + k - pad + 1;
+        if (p >= 1) {
+          int v = VT::get(Hp[k], h);
+          unsigned long long key = ((unsigned long long)(unsigned)(v + 0x40000000) << 16) | (unsigned)p;
+          ck = key > ck ? key : ck;
+        }
+      }
+    }
+    ck = row_max_u64(ck);
+    const int col_best = (int)(unsigned)(ck >> 16) - 0x40000000, col_i = (int)(ck & 0xFFFF);
+    int p1, p2, best;
+    if (strat[h] == 1) {            // INDEL: the corner
+      p1 = refLen; p2 = altLen;
+      best = __shfl(VT::get(Hp[K - 1], h), (g << 4) | 15);
+    } else if (strat[h] == 2) {     // LEADING_INDEL: last column only
+      p1 = col_i; p2 = altLen; best = col_best;
+    } else {
+      unsigned long long bk = (l == 0) ? cand_key(col_best, iabs(col_i - altLen), 0) : 0ull;
+      if (LANE_IS_ALT) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const int j = l * K + k - pad + 1;
+          if (j >= 1) { unsigned long long key = cand_key(VT::get(Hp[k], h), iabs(refLen - j), j); bk = key > bk ? key : bk; }
+        }
+      } else {
+        for (int j = l + 1; j <= ns; j += 16) {
+          unsigned long long key = cand_key(VT::get(VT::from_bits(my_log[j]), h), iabs(refLen - j), j);
+          bk = key > bk ? key : bk;
+        }
+      }
+      bk = row_max_u64(bk);
+      best = (int)(unsigned)(bk >> 24) - 0x40000000;
+      const int order = 4095 - (int)(bk & 0xFFF);
+      if (order == 0) { p1 = col_i; p2 = altLen; } else { p1 = refLen; p2 = order; }
+    }
+    if (l == 0) { a.score[pr[h]] = best; a.p1[pr[h]] = p1; a.p2[pr[h]] = p2; }
+  }
+}
+
+template <bool P16, bool LIA>
+hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, int cap, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const size_t lds = sw_lds_bytes(cap);
+#define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, P16, LIA>), dim3(n), dim3(64), lds, st, a, wb, cap); break;
+  switch (K) {
+    ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
+    ACCG_CASE(9) ACCG_CASE(10) ACCG_CASE(11) ACCG_CASE(12) ACCG_CASE(13) ACCG_CASE(14) ACCG_CASE(15) ACCG_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef ACCG_CASE
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t sw_lds_bytes(int sweep_cap) { return (size_t)8 * (sweep_cap + 1) * 4; }
+
+hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
+  if (pack16) return lane_is_alt ? launch<true, true>(K, a, wb, n, cap, s) : launch<true, false>(K, a, wb, n, cap, s);
+  return lane_is_alt ? launch<false, true>(K, a, wb, n, cap, s) : launch<false, false>(K, a, wb, n, cap, s);
+}
+
+}  // namespace accg

@@ -58,6 +58,14 @@ def load():
     L.accg_phmm_batch_results.argtypes = [vp, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_batch_destroy.argtypes = [vp]
     L.accg_counters_pack.argtypes = [C.POINTER(Counters), C.POINTER(C.c_uint64)]
+    L.accg_sw_batch_create.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    for n in ("accg_sw_batch_cells", "accg_sw_batch_algorithmic_bytes"):
+        getattr(L, n).restype = C.c_uint64
+        getattr(L, n).argtypes = [vp]
+    L.accg_sw_batch_run.argtypes = [vp]
+    L.accg_sw_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.accg_sw_batch_results.argtypes = [vp, vp, vp, vp]
+    L.accg_sw_batch_destroy.argtypes = [vp]
     L.accg_phmm_tables_f32.argtypes = [vp, vp, vp, vp]
     L.accg_phmm_tables_f64.argtypes = [vp, vp, vp, vp]
     _lib = L
@@ -150,6 +158,56 @@ class PhmmBatch:
     def close(self):
         if self.h:
             self.L.accg_phmm_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+HTC_WEIGHTS = (200, -150, -260, -11)   # htc-sw/host/common.h:19-22
+
+
+class SwBatch:
+    """Device-resident batch of independent Smith-Waterman pairs (accg_sw_batch_*).
+
+    refs / alts: uint8 matrices [n, stride] (refs may be a single row shared by every pair: stride 0);
+    ref_lens / alt_lens: int32[n]; strategies: uint8[n] or a single int."""
+
+    def __init__(self, ctx, refs, ref_lens, alts, alt_lens, strategies=0, weights=HTC_WEIGHTS, shared_ref=False):
+        self.ctx, self.L = ctx, ctx.L
+        refs = np.ascontiguousarray(refs, dtype=np.uint8)
+        alts = np.ascontiguousarray(alts, dtype=np.uint8)
+        self.n = n = int(len(alt_lens))
+        rl = np.ascontiguousarray(ref_lens, dtype=np.int32)
+        al = np.ascontiguousarray(alt_lens, dtype=np.int32)
+        st = np.full(n, strategies, np.uint8) if np.isscalar(strategies) else np.ascontiguousarray(strategies, dtype=np.uint8)
+        rstride = 0 if shared_ref else (refs.shape[1] if refs.ndim == 2 else 0)
+        astride = alts.shape[1] if alts.ndim == 2 else 0
+        self.h = C.c_void_p()
+        _check(self.L.accg_sw_batch_create(ctx.h, n, refs.ctypes.data, rstride, rl.ctypes.data, alts.ctypes.data, astride,
+                                           al.ctypes.data, st.ctypes.data, *[int(w) for w in weights], C.byref(self.h)))
+        self.cells = int(self.L.accg_sw_batch_cells(self.h))
+        self.algorithmic_bytes = int(self.L.accg_sw_batch_algorithmic_bytes(self.h))
+
+    def run(self):
+        _check(self.L.accg_sw_batch_run(self.h))
+
+    def time(self, warmup=1, iters=5):
+        ms = C.c_float()
+        _check(self.L.accg_sw_batch_time(self.h, warmup, iters, C.byref(ms)))
+        return ms.value
+
+    def results(self):
+        sc, p1, p2 = (np.zeros(self.n, np.int32) for _ in range(3))
+        _check(self.L.accg_sw_batch_results(self.h, sc.ctypes.data, p1.ctypes.data, p2.ctypes.data))
+        return sc, p1, p2
+
+    def close(self):
+        if self.h:
+            self.L.accg_sw_batch_destroy(self.h)
             self.h = C.c_void_p()
 
     def __enter__(self):

@@ -88,6 +88,28 @@ int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, fl
 int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* counters);
 void accg_phmm_batch_destroy(accg_phmm_batch* b);
 
+/* ---- HTC Smith-Waterman ------------------------------------------------------------------------
+ * GATK SWPairwiseAlignment as the reference implements it on the CPU
+ * (htc-sw/host/FalconSW_AVX.cpp: fill :1693-1823, end cell :2314-2339; weights htc-sw/host/common.h:19-22).
+ * A batch is n independent (reference window, alternate/read) pairs given as two strided byte matrices;
+ * row k of `refs` is the window of pair k (ref_lens[k] bytes used), likewise `alts`.  One ref x B alts,
+ * the shape of SWPairwiseAlignmentMultiBatch (:304) / FalconSWFPGA_run (htc-sw/host/FalconSW_FPGA.cpp:28),
+ * is the special case ref_stride = 0.
+ * Results per pair: score = sw[p1][p2] and the end cell (p1, p2) that calculateCigarOneBatch starts its
+ * backtrace from -- bit-exact with the CPU path.  (The CIGAR itself is SURVEY.md 8f row 3: next.)
+ * strategies: per pair, 0 SOFTCLIP, 1 INDEL, 2 LEADING_INDEL, 3 IGNORE (common.h:15-18); NULL = all SOFTCLIP.
+ * Limits of this round: 1 <= length <= ACCG_SW_MAX_LEN and min(ref_len, alt_len) <= ACCG_SW_MAX_SHORT. */
+#define ACCG_SW_MAX_SHORT 255
+int accg_sw_batch_create(accg_ctx* ctx, int n_pairs, const uint8_t* refs, size_t ref_stride, const int32_t* ref_lens,
+                         const uint8_t* alts, size_t alt_stride, const int32_t* alt_lens, const uint8_t* strategies,
+                         int w_match, int w_mismatch, int w_open, int w_extend, accg_sw_batch** out);
+uint64_t accg_sw_batch_cells(const accg_sw_batch* b);               /* sum ref_len * alt_len (sw_host.cpp:314) */
+uint64_t accg_sw_batch_algorithmic_bytes(const accg_sw_batch* b);   /* ref_len + alt_len + 16 per pair */
+int accg_sw_batch_run(accg_sw_batch* b);                            /* asynchronous on accg_stream() */
+int accg_sw_batch_time(accg_sw_batch* b, int warmup, int iters, float* ms_per_run);
+int accg_sw_batch_results(accg_sw_batch* b, int32_t* score, int32_t* p1, int32_t* p2);
+void accg_sw_batch_destroy(accg_sw_batch* b);
+
 /* ---- counters (multi-GPU) ---------------------------------------------------------------------
  * Packs counters into the uint64[4] {cells, pairs, kernel_ns, rescued} vector that the ranks
  * all-reduce over RCCL; the collective itself is issued by the host harness
