@@ -82,6 +82,92 @@ def cpu_baseline_phmm(reads, haps, min_wall=1.0):
                       "%.2f s wall" % (reps, wall)}
 
 
+def make_c2(rank, n=1 << 20):
+    """BASELINE configs[2]: n independent pairs, 300-bp window (rows) vs 150-bp read (cols), SOFTCLIP / IGNORE halves."""
+    from acc_genomics_amd import synth
+    rng = synth.rng_for(2 + 1000 * rank)
+    base_r, base_a = synth.make_sw_pairs(rng, 4096, 300, 150)
+    rep = n // 4096
+    perm = rng.permutation(n)
+    refs = np.tile(base_r, (rep, 1))[perm]
+    alts = np.tile(base_a, (rep, 1))[perm]
+    noise = rng.random(alts.shape) < 0.02      # every copy gets its own substitutions
+    alts[noise] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(noise.sum()))]
+    strat = (np.arange(n) % 2 * 3).astype(np.uint8)
+    return refs, np.full(n, 300, np.int32), alts, np.full(n, 150, np.int32), strat
+
+
+def cpu_baseline_sw(refs, rl, alts, al, min_wall=1.0, sample=4096):
+    """The intel_avx path BASELINE.json names (runSWOnePairBT_avx2, htc-sw/intel_avx/PairWiseSW.h:440-470, compiled in
+    place into oracle/_ref) on all host cores, over a bounded sample of the same pairs."""
+    import orc
+    if not orc.ref_available():
+        return None
+    R = orc.ref_sw()
+    n_threads = host_cores()
+    sample = min(sample, len(rl))
+    slices = [s for s in np.array_split(np.arange(sample), n_threads) if len(s)]
+
+    def work(idx):
+        r = np.ascontiguousarray(refs[idx]); a = np.ascontiguousarray(alts[idx])
+        rls = np.ascontiguousarray(rl[idx]); als = np.ascontiguousarray(al[idx])
+        offs = np.zeros(len(idx), np.int32)
+        R.ref_sw_gkl_many(r.tobytes(), r.shape[1], orc.ptr(rls, orc.i32p), a.tobytes(), a.shape[1], orc.ptr(als, orc.i32p),
+                          len(idx), 0, orc.ptr(offs, orc.i32p))
+
+    cells_once = int((rl[:sample].astype(np.int64) * al[:sample]).sum())
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        th = [threading.Thread(target=work, args=(s,)) for s in slices]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        reps += 1
+        wall = time.perf_counter() - t0
+        if wall >= min_wall:
+            break
+    return {"value": cells_once * reps / wall / 1e9, "unit": "GCUPS", "cores": n_threads, "kind": "reference",
+            "sample": "%d x %d pairs (300 vs 150) through runSWOnePairBT_avx2 (fill + backtrace, as the reference times it), %.2f s wall"
+                      % (reps, sample, wall)}
+
+
+def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
+    """Smith-Waterman leg: configs[2] on this rank's GPU; returns (cells processed, seconds, extras for rank 0)."""
+    import acc_genomics_amd as A
+    refs, rl, alts, al, strat = make_c2(rank)
+    b = A.SwBatch(ctx, refs, rl, alts, al, strategies=strat)
+    for _ in range(warmup):
+        b.run()
+    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h))
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    stream.synchronize()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    extras = None
+    if rank == 0:
+        k_ms = b.time(warmup=1, iters=max(3, steps))
+        ach = b.algorithmic_bytes / (k_ms * 1e-3) / 1e9
+        extras = {"kernel_ms": k_ms, "pairs_per_gpu": b.n, "cells_per_gpu": b.cells,
+                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
+                               "algorithmic_bytes_per_launch": b.algorithmic_bytes,
+                               "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
+                                        "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
+                  "cpu_baseline": cpu_baseline_sw(refs, rl, alts, al) if with_cpu else None}
+    cells = b.cells * steps
+    b.close()
+    return cells, t1 - t0, extras
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +175,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sw-steps", type=int, default=5, help="passes over the Smith-Waterman batch (0 = skip that leg)")
     args = ap.parse_args()
 
     import torch
@@ -141,6 +228,21 @@ def main():
     total_cells, total_pairs = int(vec[0]), int(vec[1])
     wall = float(tmax[0])
 
+    sw = None
+    if args.sw_steps > 0:
+        sw_cells, sw_t, sw_extras = bench_sw(ctx, rank, dist, torch, args.sw_steps, 1, not args.no_cpu_baseline)
+        v = torch.tensor([sw_cells], dtype=torch.int64, device="cuda")
+        tm = torch.tensor([sw_t], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            sw = {"metric": "htc_sw_gcups_int16", "value": int(v[0]) / float(tm[0]) / 1e9, "unit": "GCUPS", "steps": args.sw_steps,
+                  "ms_per_step": float(tm[0]) / args.sw_steps * 1e3, "dtype": "int16",
+                  "config": {"workload": "BASELINE.json configs[2]: 2^20 pairs per GPU, 300-bp window vs 150-bp read, "
+                                         "SOFTCLIP/IGNORE halves, weights 200/-150/-260/-11, score + end cell"}}
+            sw.update(sw_extras)
+
     line = None
     if rank == 0:
         # dominant kernel: the fp32 sweep; HIP events on the launch stream (accg_phmm_batch_time2)
@@ -168,6 +270,7 @@ def main():
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name},
             "roofline": roof, "cpu_baseline": cpu,
             "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": int(vec[3])},
+            "sw": sw,
         }
     batch.close()
     ctx.close()

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Folds the per-pass rocprofv3 counter CSVs written by tools/prof_pmc.sh into one per-kernel table (mean per dispatch)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root, tag = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "pmc_%s_*" % tag, "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        if "phmm_kernel<float" in name:
+            k = "phmm_f32"
+        elif "phmm_kernel<double" in name:
+            k = "phmm_rescue_f64"
+        elif "sw_kernel" in name:
+            k = "sw"
+        else:
+            continue
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+for k, d in out.items():
+    d["_dispatches_seen"] = max(len(v) for v in acc[k].values())
+json.dump(out, open(os.path.join(root, "pmc_%s_summary.json" % tag), "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
