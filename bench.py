@@ -218,15 +218,10 @@ def main():
     elapsed = t1 - t0
     raw, _, cnt = batch.results(want_log10=False)
 
-    # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks, wall time max over ranks
-    vec = torch.tensor([batch.cells * args.steps, batch.pairs * args.steps, int(elapsed * 1e9), int(cnt.rescued)],
-                       dtype=torch.int64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_cells, total_pairs = int(vec[0]), int(vec[1])
-    wall = float(tmax[0])
+    # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks, wall time max over ranks (RCCL)
+    from acc_genomics_amd.dist import reduce_counters
+    total_cells, total_pairs, _, total_resc, wall = reduce_counters(batch.cells * args.steps, batch.pairs * args.steps,
+                                                                    int(elapsed * 1e9), int(cnt.rescued), elapsed, dist, "cuda")
 
     sw = None
     if args.sw_steps > 0:
@@ -269,7 +264,7 @@ def main():
                                    "fp32 sweep + fp64 rescue pass, mode=%s" % args.mode,
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name},
             "roofline": roof, "cpu_baseline": cpu,
-            "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": int(vec[3])},
+            "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
             "sw": sw,
         }
     batch.close()
