@@ -22,12 +22,25 @@ struct SwArgs {
   const SwWork* work;
   int32_t* score; int32_t* p1; int32_t* p2;   // per pair
   int w_match, w_mismatch, w_open, w_extend;
+  // backtrace mode only:
+  uint4* bt;                 // decision bit planes, one uint4 per (step, lane): see sw_kernel.hip
+  uint64_t bt_item_stride;   // uint4 elements per wavefront job
+  int32_t* cig_n;            // per pair: number of elements, or -(needed) when max_el was too small, or -1 (no alignment)
+  int32_t* cig_off;          // per pair: alignment_offset
+  int32_t* cig_el;           // per pair: max_el x {length, state}
+  int32_t max_el;
 };
 
 // lane_is_alt: the lanes hold the alternate/read and the sweep runs over the reference window (else the converse).
 // pack16: two pairs per group in 16-bit halves (scores must fit int16), else one pair per group in int32.
-hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
-                     int sweep_cap, hipStream_t s);
+// with_bt: also record the per-cell decisions needed by the backtrace (a.bt); job i of the launch uses
+// a.bt + (i - bt_first) * a.bt_item_stride.
+hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
+                     uint32_t bt_first, int sweep_cap, hipStream_t s);
+// the backtrace proper (calculateCigarOneBatch, FalconSW_AVX.cpp:2303-2419): one thread per pair
+hipError_t sw_trace_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
+                           uint32_t bt_first, int sweep_cap, hipStream_t s);
 size_t sw_lds_bytes(int sweep_cap);
+inline uint64_t sw_bt_item_uint4(int sweep_cap) { return (uint64_t)4 * (sweep_cap + 16) * 16; }
 
 }  // namespace accg

@@ -1,6 +1,7 @@
 // Host side of the HTC Smith-Waterman path: batch upload, pairing/packing of pairs into wavefront jobs,
 // launches, results.  Stands in for the pair loop of SWPairwiseAlignmentMultiBatch
 // (htc-sw/host/FalconSW_AVX.cpp:304-313) up to and including the end-cell selection (:2314-2339).
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -29,6 +30,10 @@ struct accg_sw_batch {
   int32_t *d_rl = nullptr, *d_al = nullptr, *d_score = nullptr, *d_p1 = nullptr, *d_p2 = nullptr;
   SwWork* d_work = nullptr;
   SwArgs args{};
+  // backtrace mode
+  uint4* d_bt = nullptr; uint64_t bt_bytes = 0;
+  int32_t *d_cig_n = nullptr, *d_cig_off = nullptr, *d_cig_el = nullptr;
+  int max_el = 0;
 };
 
 extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, size_t ref_stride, const int32_t* ref_lens,
@@ -124,7 +129,67 @@ extern "C" int accg_sw_batch_run(accg_sw_batch* b) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   for (const SwLaunch& l : b->launches)
-    ACCG_HIP(sw_launch(l.K, l.pack16, l.lane_is_alt, b->args, l.work0, l.n_work, l.sweep_cap, b->ctx->stream));
+    ACCG_HIP(sw_launch(l.K, l.pack16, l.lane_is_alt, false, b->args, l.work0, l.n_work, l.work0, l.sweep_cap, b->ctx->stream));
+  return ACCG_OK;
+}
+
+// Fill with the per-cell decision record, then the backtrace (calculateCigarOneBatch).  The record is
+// 256 B per step per group of two pairs (40 KB per pair at configs[2]); it lives in one scratch buffer of
+// at most ACCG_SW_BT_BYTES (default 16 GiB, env) that successive slices of the job list reuse.
+extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
+  if (!b || max_el <= 0) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  hipStream_t s = b->ctx->stream;
+  const size_t n1 = (size_t)std::max(b->n, 1);
+  if (max_el != b->max_el) {
+    ACCG_HIP(hipStreamSynchronize(s));
+    if (b->d_cig_el) { hipFree(b->d_cig_el); b->d_cig_el = nullptr; }
+    ACCG_HIP(hipMalloc((void**)&b->d_cig_el, n1 * max_el * 2 * sizeof(int32_t)));
+    if (!b->d_cig_n) ACCG_HIP(hipMalloc((void**)&b->d_cig_n, n1 * sizeof(int32_t)));
+    if (!b->d_cig_off) ACCG_HIP(hipMalloc((void**)&b->d_cig_off, n1 * sizeof(int32_t)));
+    b->max_el = max_el;
+  }
+  uint64_t limit = 16ull << 30;
+  if (const char* e = getenv("ACCG_SW_BT_BYTES")) limit = strtoull(e, nullptr, 10);
+  // size the scratch for the largest slice any launch will use
+  uint64_t need = 0;
+  for (const SwLaunch& l : b->launches) {
+    const uint64_t per = sw_bt_item_uint4(l.sweep_cap) * sizeof(uint4);
+    const uint64_t items = std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, limit / per));
+    need = std::max(need, items * per);
+  }
+  if (need > b->bt_bytes) {
+    ACCG_HIP(hipStreamSynchronize(s));
+    if (b->d_bt) hipFree(b->d_bt);
+    b->d_bt = nullptr; b->bt_bytes = 0;
+    ACCG_HIP(hipMalloc((void**)&b->d_bt, need));
+    b->bt_bytes = need;
+  }
+  SwArgs a = b->args;
+  a.bt = b->d_bt; a.cig_n = b->d_cig_n; a.cig_off = b->d_cig_off; a.cig_el = b->d_cig_el; a.max_el = max_el;
+  for (const SwLaunch& l : b->launches) {
+    a.bt_item_stride = sw_bt_item_uint4(l.sweep_cap);
+    const uint64_t per = a.bt_item_stride * sizeof(uint4);
+    const uint32_t slice = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, b->bt_bytes / per));
+    for (uint32_t off = 0; off < l.n_work; off += slice) {
+      const uint32_t n = std::min(slice, l.n_work - off), w0 = l.work0 + off;
+      ACCG_HIP(sw_launch(l.K, l.pack16, l.lane_is_alt, true, a, w0, n, w0, l.sweep_cap, s));
+      ACCG_HIP(sw_trace_launch(l.K, l.pack16, l.lane_is_alt, a, w0, n, w0, l.sweep_cap, s));
+    }
+  }
+  return ACCG_OK;
+}
+
+extern "C" int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* offsets, int32_t* elements) {
+  if (!b || !b->d_cig_n) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  const size_t n = (size_t)b->n;
+  if (n) {
+    if (n_el) ACCG_HIP(hipMemcpy(n_el, b->d_cig_n, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (offsets) ACCG_HIP(hipMemcpy(offsets, b->d_cig_off, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (elements) ACCG_HIP(hipMemcpy(elements, b->d_cig_el, n * b->max_el * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
   return ACCG_OK;
 }
 
@@ -161,7 +226,8 @@ extern "C" void accg_sw_batch_destroy(accg_sw_batch* b) {
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
   for (void* p : {(void*)b->d_refs, (void*)b->d_alts, (void*)b->d_strat, (void*)b->d_rl, (void*)b->d_al, (void*)b->d_score,
-                  (void*)b->d_p1, (void*)b->d_p2, (void*)b->d_work})
+                  (void*)b->d_p1, (void*)b->d_p2, (void*)b->d_work, (void*)b->d_bt, (void*)b->d_cig_n, (void*)b->d_cig_off,
+                  (void*)b->d_cig_el})
     if (p) hipFree(p);
   delete b;
 }

@@ -53,6 +53,11 @@ template <> struct Val<true> {
   static __device__ __forceinline__ int bits(T a) { return __builtin_bit_cast(int, a); }
   static __device__ __forceinline__ T from_bits(int b) { return __builtin_bit_cast(T, b); }
   static __device__ __forceinline__ int get(T a, int half) { return half ? (int)a.y : (int)a.x; }
+  // (a < b) per half as 0/1 at bits 0 and 16: sign of the saturating difference
+  static __device__ __forceinline__ unsigned lt(T a, T b) {
+    u2 d = __builtin_bit_cast(u2, __builtin_elementwise_sub_sat(a, b));
+    return __builtin_bit_cast(unsigned, (u2)(d >> 15));
+  }
   enum { NEG = NEG16 };
 };
 template <> struct Val<false> {
@@ -65,6 +70,7 @@ template <> struct Val<false> {
   static __device__ __forceinline__ int bits(T a) { return a; }
   static __device__ __forceinline__ T from_bits(int b) { return b; }
   static __device__ __forceinline__ int get(T a, int) { return a; }
+  static __device__ __forceinline__ unsigned lt(T a, T b) { return (unsigned)(a - b) >> 31; }   // |values| < 2^30 + 2^20
   enum { NEG = NEG32 };
 };
 
@@ -92,8 +98,15 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
   return v;
 }
 
-template <int K, bool P16, bool LANE_IS_ALT>
-__global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, int sweep_cap) {
+// Backtrace record (BT = true).  Every (step t, lane) stores one uint4 = four bit planes; plane bit
+// (K-1-k) + 16*half belongs to the cell (lane position of local row k, sweep index t - lane):
+//   x: lane-direction gap OPENED here  (open > extension, strictly: FalconSW_AVX.cpp:1774 / :1786)
+//   y: sweep-direction gap OPENED here
+//   z: cell is NOT diagonal            (diag >= down && diag >= right fails, :1798)
+//   w: DOWN wins over RIGHT            (right >= down fails, :1803)
+// With the planes, btrack's +-k (:1805-1809) is the run length of not-opened cells walked by sw_trace.
+template <int K, bool P16, bool LANE_IS_ALT, bool BT>
+__global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, uint32_t bt_first, int sweep_cap) {
   typedef Val<P16> VT;
   typedef typename VT::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -176,16 +189,28 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, in
     if (i >= 1 && i <= ns) {
       const T c = VT::from_bits((int)my_ch[i]);
       T hup = h_in, hdiag = d_in, f = f_in;
+      unsigned pf = 0, pg = 0, pn = 0, pd = 0;
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const T hold = Hp[k];
-        f = VT::mx(VT::adds(f, ext), VT::adds(hup, opn[k]));            // gap along the lanes
-        G[k] = VT::mx(VT::adds(G[k], ext), VT::adds(hold, opn_s));      // gap along the sweep
+        const T fe = VT::adds(f, ext), fo = VT::adds(hup, opn[k]);
+        f = VT::mx(fe, fo);                                              // gap along the lanes
+        const T ge = VT::adds(G[k], ext), go = VT::adds(hold, opn_s);
+        G[k] = VT::mx(ge, go);                                           // gap along the sweep
         const T dg = VT::adds(hdiag, VT::score(ch[k], c, wm[k], wd[k]));
-        const T hn = VT::mx(VT::mx(dg, G[k]), f);
+        const T m = VT::mx(G[k], f);
+        const T hn = VT::mx(dg, m);
+        if (BT) {
+          pf = (pf << 1) | VT::lt(fe, fo);
+          pg = (pg << 1) | VT::lt(ge, go);
+          pn = (pn << 1) | VT::lt(dg, m);
+          pd = (pd << 1) | (LANE_IS_ALT ? VT::lt(f, G[k]) : VT::lt(G[k], f));   // right < down
+        }
         hdiag = hold; hup = hn; Hp[k] = hn;
       }
       h_last = hup; f_last = f;
+      if (BT) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + 16) + t) * 16 + l] =
+          make_uint4(pf, pg, pn, pd);
       if (l == 15) my_log[i] = VT::bits(hup);
     }
   }
@@ -250,11 +275,81 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, in
   }
 }
 
-template <bool P16, bool LIA>
-hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, int cap, hipStream_t st) {
+// ---- backtrace: one thread per pair ------------------------------------------------------------------
+// Restates calculateCigarOneBatch (FalconSW_AVX.cpp:2341-2417) on top of the bit planes: the walk, the
+// strategy-specific tail, alignment_offset and the final reversal.
+template <bool LANE_IS_ALT>
+__global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int p16, int sweep_cap) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wi = tid >> 3, slot = tid & 7;
+  if (wi >= n_work) return;
+  const uint32_t pair = a.work[work_base + wi].pair[slot];
+  const int g = slot >> 1, half = slot & 1;
+  if (pair == SW_NO_PAIR || (!p16 && half)) return;
+  const int refLen = a.ref_len[pair], altLen = a.alt_len[pair], strat = a.strategy[pair];
+  const int nl = LANE_IS_ALT ? altLen : refLen;
+  const int pad = 16 * K - nl;
+  const uint4* bt = a.bt + (uint64_t)(work_base + wi - bt_first) * a.bt_item_stride + (uint64_t)g * (sweep_cap + 16) * 16;
+  // plane p of cell (i, j) (1-based reference coordinates)
+  auto bit = [&](int i, int j, int plane) -> unsigned {
+    const int sidx = LANE_IS_ALT ? i : j, pos = LANE_IS_ALT ? j : i;
+    const int flat = pos - 1 + pad, l = flat / K, k = flat - l * K;
+    const unsigned* w = reinterpret_cast<const unsigned*>(bt + (uint64_t)(sidx + l) * 16 + l);
+    return (w[plane] >> (K - 1 - k + 16 * half)) & 1u;
+  };
+  // planes: 0 lane-direction gap opened, 1 sweep-direction gap opened; "right" (insertion) runs along the alternate
+  const int P_HOPEN = LANE_IS_ALT ? 0 : 1, P_VOPEN = LANE_IS_ALT ? 1 : 0;
+  int p1 = a.p1[pair], p2 = a.p2[pair];
+  int32_t* el = a.cig_el + (size_t)pair * a.max_el * 2;
+  const int cap = a.max_el;
+  int n = 0;
+  auto push = [&](int len, int st) {           // addCigarElement (sw_host.cpp:17-26): non-positive lengths are dropped
+    if (len <= 0) return;
+    if (n < cap) { el[2 * n] = len; el[2 * n + 1] = st; }
+    n++;
+  };
+  int seg = 0;
+  if (strat != 1 && strat != 2 && p1 == refLen && p2 != altLen) seg = altLen - p2;   // set by the bottom-row scan (:2335)
+  // (when the bottom-row scan picked j == altLen the segment is 0 as well)
+  if (seg > 0 && strat == 0) { push(seg, 4); seg = 0; }                               // soft clip, :2342-2345
+  int state = 0;
+  do {
+    int ns_ = 0, step = 1;
+    if (bit(p1, p2, 2)) {                       // not diagonal
+      if (bit(p1, p2, 3)) {                     // down: deletion of kd rows
+        ns_ = 2;
+        int r = p1;
+        while (!bit(r, p2, P_VOPEN)) { step++; r--; }
+      } else {                                  // right: insertion of ki columns
+        ns_ = 1;
+        int c = p2;
+        while (!bit(p1, c, P_HOPEN)) { step++; c--; }
+      }
+    }
+    if (ns_ == 0) { p1--; p2--; } else if (ns_ == 1) p2 -= step; else p1 -= step;
+    if (ns_ == state) seg += step;
+    else { push(seg, state); seg = step; state = ns_; }
+  } while (p1 > 0 && p2 > 0);
+  int off;
+  if (strat == 0) { push(seg, state); if (p2 > 0) push(p2, 4); off = p1; }            // :2379-2385
+  else if (strat == 3) { push(seg + p2, state); off = p1 - p2; }                      // :2386-2389
+  else { push(seg, state); if (p1 > 0) push(p1, 2); else if (p2 > 0) push(p2, 1); off = 0; }   // :2390-2400
+  a.cig_off[pair] = off;
+  if (n <= 0) { a.cig_n[pair] = -1; return; }
+  if (n > cap) { a.cig_n[pair] = -n; return; }
+  for (int x = 0, y = n - 1; x < y; x++, y--) {                                       // :2408-2417
+    int t0 = el[2 * x], t1 = el[2 * x + 1];
+    el[2 * x] = el[2 * y]; el[2 * x + 1] = el[2 * y + 1];
+    el[2 * y] = t0; el[2 * y + 1] = t1;
+  }
+  a.cig_n[pair] = n;
+}
+
+template <bool P16, bool LIA, bool BT>
+hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first, int cap, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const size_t lds = sw_lds_bytes(cap);
-#define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, P16, LIA>), dim3(n), dim3(64), lds, st, a, wb, cap); break;
+#define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, P16, LIA, BT>), dim3(n), dim3(64), lds, st, a, wb, bt_first, cap); break;
   switch (K) {
     ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
     ACCG_CASE(9) ACCG_CASE(10) ACCG_CASE(11) ACCG_CASE(12) ACCG_CASE(13) ACCG_CASE(14) ACCG_CASE(15) ACCG_CASE(16)
@@ -268,9 +363,28 @@ hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, int cap, hipS
 
 size_t sw_lds_bytes(int sweep_cap) { return (size_t)8 * (sweep_cap + 1) * 4; }
 
-hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
-  if (pack16) return lane_is_alt ? launch<true, true>(K, a, wb, n, cap, s) : launch<true, false>(K, a, wb, n, cap, s);
-  return lane_is_alt ? launch<false, true>(K, a, wb, n, cap, s) : launch<false, false>(K, a, wb, n, cap, s);
+hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t wb, uint32_t n,
+                     uint32_t bt_first, int cap, hipStream_t s) {
+  const int sel = (pack16 ? 4 : 0) | (lane_is_alt ? 2 : 0) | (with_bt ? 1 : 0);
+  switch (sel) {
+    case 0: return launch<false, false, false>(K, a, wb, n, bt_first, cap, s);
+    case 1: return launch<false, false, true>(K, a, wb, n, bt_first, cap, s);
+    case 2: return launch<false, true, false>(K, a, wb, n, bt_first, cap, s);
+    case 3: return launch<false, true, true>(K, a, wb, n, bt_first, cap, s);
+    case 4: return launch<true, false, false>(K, a, wb, n, bt_first, cap, s);
+    case 5: return launch<true, false, true>(K, a, wb, n, bt_first, cap, s);
+    case 6: return launch<true, true, false>(K, a, wb, n, bt_first, cap, s);
+    default: return launch<true, true, true>(K, a, wb, n, bt_first, cap, s);
+  }
+}
+
+hipError_t sw_trace_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first,
+                           int cap, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const uint32_t threads = n * 8, block = 64, grid = (threads + block - 1) / block;
+  if (lane_is_alt) hipLaunchKernelGGL((sw_trace_kernel<true>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, (int)pack16, cap);
+  else hipLaunchKernelGGL((sw_trace_kernel<false>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, (int)pack16, cap);
+  return hipGetLastError();
 }
 
 }  // namespace accg

@@ -66,6 +66,8 @@ def load():
     L.accg_sw_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_sw_batch_results.argtypes = [vp, vp, vp, vp]
     L.accg_sw_batch_destroy.argtypes = [vp]
+    L.accg_sw_batch_run_cigar.argtypes = [vp, C.c_int]
+    L.accg_sw_batch_cigars.argtypes = [vp, vp, vp, vp]
     L.accg_phmm_tables_f32.argtypes = [vp, vp, vp, vp]
     L.accg_phmm_tables_f64.argtypes = [vp, vp, vp, vp]
     _lib = L
@@ -204,6 +206,17 @@ class SwBatch:
         sc, p1, p2 = (np.zeros(self.n, np.int32) for _ in range(3))
         _check(self.L.accg_sw_batch_results(self.h, sc.ctypes.data, p1.ctypes.data, p2.ctypes.data))
         return sc, p1, p2
+
+    def run_cigar(self, max_el=64):
+        self.max_el = max_el
+        _check(self.L.accg_sw_batch_run_cigar(self.h, max_el))
+
+    def cigars(self):
+        """-> (n_el int32[n], alignment_offset int32[n], elements int32[n, max_el, 2] as (length, state))."""
+        n_el, off = np.zeros(self.n, np.int32), np.zeros(self.n, np.int32)
+        el = np.zeros((self.n, self.max_el, 2), np.int32)
+        _check(self.L.accg_sw_batch_cigars(self.h, n_el.ctypes.data, off.ctypes.data, el.ctypes.data))
+        return n_el, off, el
 
     def close(self):
         if self.h:

@@ -108,6 +108,13 @@ uint64_t accg_sw_batch_algorithmic_bytes(const accg_sw_batch* b);   /* ref_len +
 int accg_sw_batch_run(accg_sw_batch* b);                            /* asynchronous on accg_stream() */
 int accg_sw_batch_time(accg_sw_batch* b, int warmup, int iters, float* ms_per_run);
 int accg_sw_batch_results(accg_sw_batch* b, int32_t* score, int32_t* p1, int32_t* p2);
+/* Fill + end cell + backtrace: the whole of SWPairwiseAlignmentOneBatch (FalconSW_AVX.cpp:315-411).  Per pair at
+ * most max_el CIGAR elements {length, state} in final (forward) order, states as htc-sw/host/common.h:23-26
+ * (M 0, I 1, D 2, S 4), and alignment_offset (:2379-2401).  accg_sw_batch_results is valid afterwards too. */
+int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el);
+/* n_el[k] > 0: element count; -1: calculateCigarOneBatch's "no element" failure (:2404-2407);
+ * < -1: -(elements needed) > max_el, rerun with a larger max_el.  elements: int32[n][max_el][2]. */
+int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* alignment_offsets, int32_t* elements);
 void accg_sw_batch_destroy(accg_sw_batch* b);
 
 /* ---- counters (multi-GPU) ---------------------------------------------------------------------

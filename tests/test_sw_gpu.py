@@ -158,3 +158,91 @@ def test_error_paths(ctx):
         b.run()
         sc, p1, p2 = b.results()
     assert (sc[0], p1[0], p2[0]) == (800, 4, 4)
+
+
+# ---- backtrace / CIGAR (calculateCigarOneBatch, FalconSW_AVX.cpp:2303-2419) ------------------------------
+def _oracle_cigar(ref, alt, s, w=A.HTC_WEIGHTS):
+    sc, p1, p2, off, cig, n = orc.sw_pair(orc.oracle(), ref, alt, s, w, max_el=4096)
+    return n, off, cig
+
+
+@pytest.mark.parametrize("path", SW, ids=[os.path.basename(p)[:-4] for p in SW])
+def test_golden_cigars(ctx, path):
+    g = np.load(path)
+    refs, alts = g["refs"], g["alts"]
+    n = refs.shape[0]
+    rl, al = np.full(n, refs.shape[1], np.int32), np.full(n, alts.shape[1], np.int32)
+    for s in range(4):
+        with A.SwBatch(ctx, refs, rl, alts, al, strategies=s) as b:
+            b.run_cigar(64)
+            n_el, off, el = b.cigars()
+            sc, p1, p2 = b.results()
+        assert np.array_equal(sc, g["score"][s]) and np.array_equal(p1, g["p1"][s]) and np.array_equal(p2, g["p2"][s])
+        assert np.array_equal(n_el, g["n_el"][s]), s
+        assert np.array_equal(off, g["offset"][s]), s
+        for k in range(n):
+            assert np.array_equal(el[k, :n_el[k], 0], g["cig_len"][s, k, :n_el[k]]), (s, k)
+            assert np.array_equal(el[k, :n_el[k], 1], g["cig_state"][s, k, :n_el[k]]), (s, k)
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 1, 40), (10, 80, 100, 400), (100, 400, 10, 80), (200, 255, 200, 255),
+                                   (250, 255, 900, 1535), (17, 17, 300, 300)])
+def test_ragged_cigars(ctx, shape):
+    rng = synth.rng_for(500 + shape[0] + shape[2])
+    n = 61
+    refs, rl, alts, al = _ragged(rng, n, *shape)
+    strat = rng.integers(0, 4, size=n).astype(np.uint8)
+    with A.SwBatch(ctx, refs, rl, alts, al, strategies=strat) as b:
+        b.run_cigar(96)
+        n_el, off, el = b.cigars()
+    for k in range(n):
+        wn, woff, wcig = _oracle_cigar(refs[k, :rl[k]].tobytes(), alts[k, :al[k]].tobytes(), int(strat[k]))
+        assert n_el[k] == wn, (shape, k)
+        if wn > 0:
+            assert off[k] == woff
+            assert list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig, (shape, k)
+
+
+def test_cigar_scratch_slicing_and_overflow(ctx, monkeypatch):
+    """A scratch budget smaller than the batch forces several fill+trace slices; a too small max_el is reported."""
+    rng = synth.rng_for(520)
+    refs, alts = synth.make_sw_pairs(rng, 300, 120, 60, indel_rate=0.05)
+    rl, al = np.full(300, 120, np.int32), np.full(300, 60, np.int32)
+    monkeypatch.setenv("ACCG_SW_BT_BYTES", str(1 << 20))
+    with A.SwBatch(ctx, refs, rl, alts, al, strategies=0) as b:
+        b.run_cigar(64)
+        n_el, off, el = b.cigars()
+        b.run_cigar(2)
+        n2, _, _ = b.cigars()
+    for k in range(300):
+        wn, woff, wcig = _oracle_cigar(refs[k].tobytes(), alts[k].tobytes(), 0)
+        assert (n_el[k], off[k]) == (wn, woff)
+        assert list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig
+        assert n2[k] == (wn if wn <= 2 else -wn)
+    assert (n2 < -1).any()
+
+
+def test_full_size_c2_cigar_properties(ctx):
+    """2^18 pairs of configs[2] through fill + backtrace: a CIGAR consumes exactly the read
+    (M + I + S = altLen) and, from alignment_offset, stays inside the window (M + D <= refLen - offset);
+    a sample is compared with the oracle."""
+    rng = synth.rng_for(3)
+    n = 1 << 18
+    base_r, base_a = synth.make_sw_pairs(rng, 2048, 300, 150, indel_rate=0.02)
+    perm0 = rng.permutation(n)
+    refs = np.tile(base_r, (n // 2048, 1))[perm0]; alts = np.tile(base_a, (n // 2048, 1))[perm0]
+    rl, al = np.full(n, 300, np.int32), np.full(n, 150, np.int32)
+    with A.SwBatch(ctx, refs, rl, alts, al, strategies=0) as b:
+        b.run_cigar(48)
+        n_el, off, el = b.cigars()
+    assert (n_el > 0).all()
+    mask = np.arange(48)[None, :] < n_el[:, None]
+    ln, st = el[:, :, 0] * mask, el[:, :, 1]
+    read_len = (ln * np.isin(st, (0, 1, 4))).sum(1)
+    ref_span = (ln * np.isin(st, (0, 2))).sum(1)
+    assert (read_len == 150).all()
+    assert (off >= 0).all() and (off + ref_span <= 300).all()
+    for k in rng.choice(n, 200, replace=False):
+        wn, woff, wcig = _oracle_cigar(refs[k].tobytes(), alts[k].tobytes(), 0)
+        assert (n_el[k], off[k]) == (wn, woff)
+        assert list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig
