@@ -1,0 +1,210 @@
+// See accg_compat.h.  Everything here is host glue over include/accg.h; no arithmetic of the hot path
+// happens on the CPU.
+#include "accg_compat.h"
+#include <string.h>
+#include <stdexcept>
+#include "../../../include/accg.h"
+
+// ---- wire format (pairhmm/interface/PairHMMHostInterface.cpp:175-338) -----------------------------
+namespace {
+struct Writer {
+  char* p; uint64_t n = 0;
+  void put(const void* s, size_t b) { if (p) memcpy(p + n, s, b); n += b; }
+  void i32(int v) { put(&v, 4); }
+};
+uint64_t write_reads(char* buf, const read_t* r, int num) {
+  Writer w{buf};
+  w.i32(num);
+  for (int i = 0; i < num; i++) {
+    w.i32(r[i].len);
+    const char* f[5] = {r[i]._b, r[i]._q, r[i]._i, r[i]._d, r[i]._c};
+    for (const char* s : f) w.put(s, (size_t)r[i].len);
+  }
+  return w.n;
+}
+uint64_t write_haps(char* buf, const hap_t* h, int num) {
+  Writer w{buf};
+  w.i32(num);
+  for (int i = 0; i < num; i++) { w.i32(h[i].len); w.put(h[i]._b, (size_t)h[i].len); }
+  return w.n;
+}
+char* take(const char*& p, int len) {   // malloc(len+1), NUL-terminated, as getStr (:34-41); NULL for len == 0
+  if (len <= 0) return nullptr;
+  char* d = (char*)malloc((size_t)len + 1);
+  memcpy(d, p, (size_t)len); d[len] = '\0'; p += len;
+  return d;
+}
+int get_i32(const char*& p) { int v; memcpy(&v, p, 4); p += 4; return v; }
+}  // namespace
+
+void free_reads(read_t* r, int n) {
+  for (int i = 0; i < n; i++) { free(r[i]._b); free(r[i]._q); free(r[i]._i); free(r[i]._d); free(r[i]._c); }
+  free(r);
+}
+void free_haps(hap_t* h, int n) { for (int i = 0; i < n; i++) free(h[i]._b); free(h); }
+uint64_t serialize(void* buf, const read_t* reads, int num) { return write_reads((char*)buf, reads, num); }
+uint64_t serialize(void* buf, const hap_t* haps, int num) { return write_haps((char*)buf, haps, num); }
+std::string serialize(const read_t* reads, int num) { std::string s(write_reads(nullptr, reads, num), '\0'); write_reads(&s[0], reads, num); return s; }
+std::string serialize(const hap_t* haps, int num) { std::string s(write_haps(nullptr, haps, num), '\0'); write_haps(&s[0], haps, num); return s; }
+int deserialize(const void* buf, read_t*& reads) {
+  const char* p = (const char*)buf;
+  int num = get_i32(p);
+  reads = (read_t*)malloc(sizeof(read_t) * (size_t)(num > 0 ? num : 1));
+  for (int i = 0; i < num; i++) {
+    int len = get_i32(p);
+    reads[i].len = len;
+    reads[i]._b = take(p, len); reads[i]._q = take(p, len); reads[i]._i = take(p, len); reads[i]._d = take(p, len); reads[i]._c = take(p, len);
+  }
+  return num;
+}
+int deserialize(const void* buf, hap_t*& haps) {
+  const char* p = (const char*)buf;
+  int num = get_i32(p);
+  haps = (hap_t*)malloc(sizeof(hap_t) * (size_t)(num > 0 ? num : 1));
+  for (int i = 0; i < num; i++) { int len = get_i32(p); haps[i].len = len; haps[i]._b = take(p, len); }
+  return num;
+}
+int deserialize(const std::string& data, read_t*& reads) { return deserialize((const void*)data.data(), reads); }
+int deserialize(const std::string& data, hap_t*& haps) { return deserialize((const void*)data.data(), haps); }
+
+// ---- one lazily created context per process (the reference keeps a global OpenCLEnv, PairHMMFpga.cpp:8) ----
+namespace {
+accg_ctx* g_ctx = nullptr;
+float* g_ret = nullptr;
+size_t g_ret_n = 0;
+accg_ctx* ctx() {
+  if (!g_ctx) {
+    const char* d = getenv("ACCG_DEVICE");
+    int st = accg_init(d ? atoi(d) : 0, &g_ctx);
+    if (st != ACCG_OK) throw std::runtime_error(std::string("accg_init: ") + accg_strerror(st));
+  }
+  return g_ctx;
+}
+bool is_capability_error(int st) { return st == ACCG_ERR_TOO_LONG || st == ACCG_ERR_BAD_BASE || st == ACCG_ERR_EMPTY_SEQ; }
+}  // namespace
+
+double peak_kernel_gcups = 0;
+double curr_kernel_gcups = 0;
+
+float* compute_fpga(const char*, std::string read_data, std::string hap_data, uint64_t num_cell) {
+  int nr = 0, nh = 0;
+  if (read_data.size() >= 4) memcpy(&nr, read_data.data(), 4);
+  if (hap_data.size() >= 4) memcpy(&nh, hap_data.data(), 4);
+  size_t need = (size_t)MAX_RSDATA_NUM * MAX_HAPDATA_NUM;   // PairHMMFpga.cpp:153-157
+  if ((size_t)nr * nh > need) need = (size_t)nr * nh;
+  if (need > g_ret_n) { free(g_ret); g_ret = (float*)aligned_alloc(4096, sizeof(float) * need); g_ret_n = need; }
+  accg_counters c;
+  int st = accg_phmm_region(ctx(), read_data.data(), read_data.size(), hap_data.data(), hap_data.size(), ACCG_PHMM_FAST,
+                            g_ret, nullptr, &c);
+  if (is_capability_error(st)) return NULL;
+  if (st != ACCG_OK) throw std::runtime_error(std::string("compute_fpga: ") + accg_strerror(st) + " " + accg_last_hip_error());
+  if (c.kernel_ns) {
+    curr_kernel_gcups = (double)num_cell / (double)c.kernel_ns;                          // PairHMMFpga.cpp:90-96
+    if (curr_kernel_gcups > peak_kernel_gcups) peak_kernel_gcups = curr_kernel_gcups;
+  }
+  return g_ret;
+}
+void cleanup() { if (g_ctx) accg_shutdown(g_ctx); g_ctx = nullptr; free(g_ret); g_ret = nullptr; g_ret_n = 0; }
+
+// ---- FalconPairHMM ----------------------------------------------------------------------------------
+FalconPairHMM::FalconPairHMM() : ctx_(nullptr), kernel_ns_(0) {
+  const char* d = getenv("ACCG_DEVICE");
+  int st = accg_init(d ? atoi(d) : 0, &ctx_);
+  if (st != ACCG_OK) throw std::runtime_error(std::string("FalconPairHMM: ") + accg_strerror(st));
+}
+FalconPairHMM::FalconPairHMM(char*) : FalconPairHMM() {}
+FalconPairHMM::~FalconPairHMM() { accg_shutdown(ctx_); }
+double FalconPairHMM::get_kernel_time() { return kernel_ns_; }
+void FalconPairHMM::computePairhmm(pairhmmInput* in, pairhmmOutput* out, bool& usedFPGA) {
+  std::vector<read_t> r(in->reads.size());
+  std::vector<hap_t> h(in->haps.size());
+  for (size_t i = 0; i < r.size(); i++) {
+    Read& x = in->reads[i];
+    r[i] = {(int)x.bases.size(), &x.bases[0], &x._q[0], &x._i[0], &x._d[0], &x._c[0]};
+  }
+  for (size_t j = 0; j < h.size(); j++) h[j] = {(int)in->haps[j].bases.size(), &in->haps[j].bases[0]};
+  std::string rs = serialize(r.data(), (int)r.size()), hs = serialize(h.data(), (int)h.size());
+  out->likelihoodData.assign(r.size() * h.size(), 0.0);
+  accg_counters c;
+  int st = accg_phmm_region(ctx_, rs.data(), rs.size(), hs.data(), hs.size(), ACCG_PHMM_FAST, nullptr,
+                            out->likelihoodData.data(), &c);
+  usedFPGA = (st == ACCG_OK);
+  if (st == ACCG_OK) { kernel_ns_ += (double)c.kernel_ns; return; }
+  out->likelihoodData.clear();
+  if (!is_capability_error(st)) throw std::runtime_error(std::string("computePairhmm: ") + accg_strerror(st));
+}
+
+// ---- HTC Smith-Waterman -------------------------------------------------------------------------------
+namespace {
+// one ref x B alts -> CIGARs; returns device ns, or -1 when the device cannot take the batch
+double sw_batch(const char* ref, int refLength, const char* alts, size_t alt_stride, const int* altLengths, int B, int strategy,
+                int wm, int wx, int wo, int we, struct Cigar* cig, int* offs) {
+  if (B <= 0) return 0;
+  std::vector<int32_t> rl((size_t)B, refLength);
+  std::vector<uint8_t> st((size_t)B, (uint8_t)strategy);
+  accg_sw_batch* b = nullptr;
+  int rc = accg_sw_batch_create(ctx(), B, (const uint8_t*)ref, 0, rl.data(), (const uint8_t*)alts, alt_stride, altLengths, st.data(),
+                                wm, wx, wo, we, &b);
+  if (is_capability_error(rc)) return -1;
+  if (rc != ACCG_OK) throw std::runtime_error(std::string("accg_sw_batch_create: ") + accg_strerror(rc));
+  int max_el = 64;
+  std::vector<int32_t> n_el((size_t)B), el;
+  float ms = 0;
+  for (;;) {
+    rc = accg_sw_batch_run_cigar(b, max_el);
+    el.resize((size_t)B * max_el * 2);
+    if (rc == ACCG_OK) rc = accg_sw_batch_cigars(b, n_el.data(), offs, el.data());
+    if (rc != ACCG_OK) { accg_sw_batch_destroy(b); throw std::runtime_error(std::string("sw run: ") + accg_strerror(rc)); }
+    int need = 0;
+    for (int k = 0; k < B; k++) if (n_el[k] < -1 && -n_el[k] > need) need = -n_el[k];
+    if (!need) break;
+    max_el = need;                                   // a CIGAR longer than the slot: rerun with room (<= MAX_SEQ_LENGTH)
+  }
+  accg_sw_batch_time(b, 0, 1, &ms);                  // score-only pass timing as the kernel-time figure
+  for (int k = 0; k < B; k++) {
+    cig[k].CigarElementNum = n_el[k] > 0 ? n_el[k] : 0;
+    for (int e = 0; e < cig[k].CigarElementNum; e++) {
+      cig[k].cigarElements[e].length = el[((size_t)k * max_el + e) * 2];
+      cig[k].cigarElements[e].state = el[((size_t)k * max_el + e) * 2 + 1];
+    }
+  }
+  accg_sw_batch_destroy(b);
+  return (double)ms * 1e6;
+}
+}  // namespace
+
+bool FalconSWFPGA_init(char*) { try { ctx(); return true; } catch (const std::exception&) { return false; } }
+void FalconSWFPGA_release() {}
+double FalconSWFPGA_run(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int* altLengths, int batchSize, int strategy,
+                        int wm, int wx, int wo, int we, struct Cigar* cig, int* offs, bool isFPGA) {
+  if (!isFPGA || batchSize <= 0) return -1;
+  return sw_batch(ref, refLength, &alts[0][0], MAX_SEQ_LENGTH, altLengths, batchSize, strategy, wm, wx, wo, we, cig, offs);
+}
+int SWPairwiseAlignmentMultiBatch(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int batchSize, int* altLengths,
+                                  struct Cigar* cig, int* offs, int strategy, int /*option: CPU variant selector*/) {
+  double ns = sw_batch(ref, refLength, &alts[0][0], MAX_SEQ_LENGTH, altLengths, batchSize, strategy, W_MATCH, W_MISMATCH, W_OPEN,
+                       W_EXTEND, cig, offs);
+  if (ns < 0) return -1;
+  for (int k = 0; k < batchSize; k++) if (cig[k].CigarElementNum <= 0) return -1;   // FalconSW_AVX.cpp:307-310
+  return 0;
+}
+void _smithWatermanRun(char* inputs, int refLength, int B, int strategy, int wm, int wx, int wo, int we, short* outputs) {
+  const int S = 512;                                 // MAX_FPGA_SEQ_LENGTH, FalconSW_FPGA.cpp:14
+  std::vector<int> al((size_t)B), offs((size_t)B);
+  for (int i = 0; i < B; i++) al[i] = (int)(unsigned char)inputs[2 * i] | ((int)(signed char)inputs[2 * i + 1] << 8);   // :54-57
+  const char* ref = inputs + 2 * B;
+  const char* alts = ref + S;
+  std::vector<struct Cigar> cig((size_t)B);
+  if (sw_batch(ref, refLength, alts, S, al.data(), B, strategy, wm, wx, wo, we, cig.data(), offs.data()) < 0)
+    throw std::runtime_error("_smithWatermanRun: batch outside the device limits");
+  int p = B + 2;
+  for (int i = 0; i < B; i++) {
+    outputs[2 + i] = (short)cig[i].CigarElementNum;
+    for (int e = cig[i].CigarElementNum - 1; e >= 0; e--) {       // reverse order, reader at :83-86
+      outputs[p++] = (short)cig[i].cigarElements[e].length;
+      outputs[p++] = (short)cig[i].cigarElements[e].state;
+    }
+    outputs[p++] = (short)offs[i];
+  }
+  outputs[0] = (short)(p & 0xFFFF); outputs[1] = (short)((unsigned)p >> 16);
+}

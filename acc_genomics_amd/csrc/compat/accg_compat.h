@@ -1,0 +1,94 @@
+// Host-side mirror of the reference's own entry points for the hot path, implemented on the C ABI
+// (include/accg.h).  Names, argument meaning, ownership and error behaviour follow the reference so
+// that its callers and its test drivers compile against this header unchanged:
+//   read_t / hap_t, serialize / deserialize, free_reads / free_haps   pairhmm/interface/PairHMMHostInterface.h:27-83
+//   compute_fpga, curr/peak_kernel_gcups, cleanup                      pairhmm/host/PairHMMFpga.h:13-22
+//   Read / Hap / pairhmmInput / pairhmmOutput, FalconPairHMM           pairhmm/xlnx/host/host_type.h:100-119, FalconPairHMM.h:17-27
+//   struct Cigar / CigarElement, weights, strategies                   htc-sw/host/common.h:13-57
+//   FalconSWFPGA_init / _run / _release                                htc-sw/host/FalconSW_FPGA.cpp:16,28,92
+//   _smithWatermanRun (byte contract of the FPGA kernel)               htc-sw/host/smithWatermanHost.h:14, FalconSW_FPGA.cpp:53-88
+//   SWPairwiseAlignmentMultiBatch                                      htc-sw/host/FalconSW_AVX.cpp:304
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+// ---- PairHMM wire types ---------------------------------------------------------------------------
+typedef struct { int len; char* _b; char* _q; char* _i; char* _d; char* _c; } read_t;
+typedef struct { int len; char* _b; } hap_t;
+void free_reads(read_t* r, int n);
+void free_haps(hap_t* h, int n);
+uint64_t serialize(void* buf, const read_t* reads, int num);
+uint64_t serialize(void* buf, const hap_t* haps, int num);
+int deserialize(const void* buf, read_t*& reads);
+int deserialize(const void* buf, hap_t*& haps);
+std::string serialize(const read_t* reads, int num);
+std::string serialize(const hap_t* haps, int num);
+int deserialize(const std::string& data, read_t*& reads);
+int deserialize(const std::string& data, hap_t*& haps);
+
+#define MAX_READ_LEN 192      /* pairhmm/xlnx/common/common.h:3-6: limits of the FPGA bundle, kept for callers */
+#define MAX_HAP_LEN 1024
+#define MAX_RSDATA_NUM 2048
+#define MAX_HAPDATA_NUM 128
+
+// ---- compute_fpga ---------------------------------------------------------------------------------
+extern double peak_kernel_gcups;
+extern double curr_kernel_gcups;
+// Returns a library-owned float[>= num_read*num_hap], row-major [read][hap], raw likelihood x 2^120;
+// NULL = this batch cannot run on the device (caller falls back, host/main.cpp:330-333); throws
+// std::runtime_error on a device failure.  Not re-entrant (as the reference: globals).
+float* compute_fpga(const char* bit_path, std::string read_data, std::string hap_data, uint64_t num_cell);
+void cleanup();
+
+// ---- FalconPairHMM --------------------------------------------------------------------------------
+typedef struct { std::string bases, _q, _i, _d, _c; } Read;
+typedef struct { std::string bases; } Hap;
+typedef struct { std::vector<Read> reads; std::vector<Hap> haps; } pairhmmInput;
+typedef struct { std::vector<double> likelihoodData; } pairhmmOutput;
+struct accg_ctx;
+class FalconPairHMM {
+ public:
+  FalconPairHMM();
+  explicit FalconPairHMM(char* bitstream);   // the argument selects nothing here; device 0 (or ACCG_DEVICE)
+  ~FalconPairHMM();
+  // final log10 likelihoods, index read*numHap + hap; usedFPGA = the device computed them
+  void computePairhmm(pairhmmInput* input, pairhmmOutput* output, bool& usedFPGA);
+  double get_kernel_time();                  // accumulated device ns
+ private:
+  accg_ctx* ctx_;
+  double kernel_ns_;
+};
+
+// ---- HTC Smith-Waterman ---------------------------------------------------------------------------
+#define MAX_SEQ_LENGTH 1536
+#define MAX_BATCH_SIZE 260
+#define OVERHANG_STRATEGY_SOFTCLIP 0
+#define OVERHANG_STRATEGY_INDEL 1
+#define OVERHANG_STRATEGY_LEADING_INDEL 2
+#define OVERHANG_STRATEGY_IGNORE 3
+#define W_MATCH 200
+#define W_MISMATCH -150
+#define W_OPEN -260
+#define W_EXTEND -11
+#define STATE_MATCH 0
+#define STATE_INSERTION 1
+#define STATE_DELETION 2
+#define STATE_CLIP 4
+struct CigarElement { int length; int state; };
+struct Cigar { struct CigarElement cigarElements[MAX_SEQ_LENGTH]; int CigarElementNum; };
+
+bool FalconSWFPGA_init(char* bitstream);
+// Returns device time in ns.  Results in place; sequences the device cannot take (min length > 255)
+// make it return -1 with nothing written (the reference falls back to its AVX code at this point).
+double FalconSWFPGA_run(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int* altLengths, int batchSize,
+                        int overhang_strategy, int w_match, int w_mismatch, int w_open, int w_extend,
+                        struct Cigar* cigarResults, int* alignmentOffsets, bool isFPGA);
+void FalconSWFPGA_release();
+// inputs: 2*B bytes of little-endian int16 alt lengths, 512 B ref, B x 512 B alts; outputs: shorts
+// [0..1] total length (32 bit), [2..2+B) element counts, then per alt (len,state)* in reverse order + alignment_offset.
+void _smithWatermanRun(char* inputs, int refLength, int batchSize, int overhang_strategy, int w_match, int w_mismatch,
+                       int w_open, int w_extend, short* outputs);
+int SWPairwiseAlignmentMultiBatch(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int batchSize, int* altLengths,
+                                  struct Cigar* cigarResults, int* alignmentOffsets, int overhang_strategy, int option);

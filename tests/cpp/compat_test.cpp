@@ -1,0 +1,122 @@
+// Drives the reference-shaped entry points of libaccg_compat.so the way the reference's own test
+// mains do (pairhmm/xlnx/pairhmm_test.cpp:60-82,237-267 --syn flow; htc-sw/host/sw_host.cpp:145-182,
+// 106-134,240-300), with the CPU oracle in the role the reference gives its AVX path.
+// Exit code 0 = every comparison passed.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <random>
+#include <string>
+#include <vector>
+#include "../../acc_genomics_amd/csrc/compat/accg_compat.h"
+#include "../../oracle/oracle.h"
+
+static std::mt19937_64 rng(0xACC6E0);
+static char base() { return "ACGT"[rng() % 4]; }
+static int clampi(double v, int lo, int hi) { int x = (int)lround(v); return x < lo ? lo : x > hi ? hi : x; }
+
+static int test_pairhmm() {
+  int bad = 0;
+  FalconPairHMM falcon;
+  std::normal_distribution<double> q(30, 5), g(40, 1);
+  for (int iter = 0; iter < 6; iter++) {            // 16*(i+1) reads x (i+1) haps, as GenInputs (pairhmm_test.cpp:60-82)
+    pairhmmInput in;
+    int nh = iter + 1, nr = 16 * (iter + 1);
+    for (int j = 0; j < nh; j++) { Hap h; int len = 60 + (int)(rng() % 300); for (int k = 0; k < len; k++) h.bases.push_back(base()); in.haps.push_back(h); }
+    for (int i = 0; i < nr; i++) {
+      Read r; const std::string& src = in.haps[rng() % nh].bases;
+      int len = 20 + (int)(rng() % 130); if (len > (int)src.size()) len = (int)src.size();
+      int off = (int)(rng() % (src.size() - len + 1));
+      bool junk = rng() % 5 == 0;
+      for (int k = 0; k < len; k++) {
+        r.bases.push_back(junk || rng() % 25 == 0 ? base() : src[off + k]);
+        r._q.push_back((char)clampi(q(rng), 6, 60)); r._i.push_back((char)clampi(g(rng), 1, 60));
+        r._d.push_back((char)clampi(g(rng), 1, 60)); r._c.push_back((char)10);
+      }
+      in.reads.push_back(r);
+    }
+    pairhmmOutput out; bool used = false;
+    falcon.computePairhmm(&in, &out, used);
+    if (!used || out.likelihoodData.size() != (size_t)nr * nh) { printf("pairhmm iter %d: device not used\n", iter); return 1; }
+    // compute_fpga on the serialized form of the same region, post-processed like PairHMMWorker::getOutput
+    std::vector<read_t> rt(nr); std::vector<hap_t> ht(nh);
+    for (int i = 0; i < nr; i++) { Read& x = in.reads[i]; rt[i] = {(int)x.bases.size(), &x.bases[0], &x._q[0], &x._i[0], &x._d[0], &x._c[0]}; }
+    for (int j = 0; j < nh; j++) ht[j] = {(int)in.haps[j].bases.size(), &in.haps[j].bases[0]};
+    std::string rs = serialize(rt.data(), nr), hs = serialize(ht.data(), nh);
+    read_t* rback; hap_t* hback;
+    if (deserialize(rs, rback) != nr || deserialize(hs, hback) != nh) { printf("deserialize count\n"); return 1; }
+    for (int i = 0; i < nr; i++) if (rback[i].len != rt[i].len || memcmp(rback[i]._d, rt[i]._d, rt[i].len) || rback[i]._b[rt[i].len] != 0) bad++;
+    free_reads(rback, nr); free_haps(hback, nh);
+    uint64_t cells = 0; for (int i = 0; i < nr; i++) for (int j = 0; j < nh; j++) cells += (uint64_t)rt[i].len * ht[j].len;
+    float* raw = compute_fpga("unused.xclbin", rs, hs, cells);
+    if (!raw) { printf("compute_fpga skipped\n"); return 1; }
+    for (int i = 0; i < nr; i++)
+      for (int j = 0; j < nh; j++) {
+        const Read& r = in.reads[i]; const std::string& h = in.haps[j].bases;
+        float f = orc_phmm_forward_f32((int)r.bases.size(), (int)h.size(), r.bases.data(), r._q.data(), r._i.data(), r._d.data(), r._c.data(), h.data(), 0);
+        double want = orc_phmm_finish(f, (int)r.bases.size(), (int)h.size(), r.bases.data(), r._q.data(), r._i.data(), r._d.data(), r._c.data(), h.data(), NULL);
+        double got = out.likelihoodData[(size_t)i * nh + j];
+        if (!(fabs((got - want) / want) <= 1e-5) || got != got) { if (bad < 5) printf("pairhmm %d,%d: %.9g vs %.9g\n", i, j, got, want); bad++; }
+        float fr = raw[(size_t)i * nh + j];
+        if (f > 1e-27f && !(fabs((fr - f) / f) <= 1e-5)) { if (bad < 5) printf("compute_fpga raw %d,%d: %g vs %g\n", i, j, fr, f); bad++; }
+      }
+  }
+  printf("pairhmm: %s (kernel %.0f ns, peak %.1f GCUPS)\n", bad ? "FAILED" : "ok", falcon.get_kernel_time(), peak_kernel_gcups);
+  return bad;
+}
+
+static int cmp_cigar(const struct Cigar& c, int off, const char* ref, int rl, const char* alt, int al, int strategy, const int* w) {
+  int sc, p1, p2, woff; static int wl[4096], ws[4096];
+  int n = orc_sw_pair(ref, alt, rl, al, strategy, w[0], w[1], w[2], w[3], &sc, &p1, &p2, 4096, wl, ws, &woff);
+  if (n <= 0) return c.CigarElementNum == 0 ? 0 : 1;
+  if (n != c.CigarElementNum || off != woff) return 1;
+  for (int e = 0; e < n; e++) if (c.cigarElements[e].length != wl[e] || c.cigarElements[e].state != ws[e]) return 1;
+  return 0;
+}
+
+static int test_sw() {
+  int bad = 0;
+  static char alts[MAX_BATCH_SIZE][MAX_SEQ_LENGTH];
+  static struct Cigar cig[MAX_BATCH_SIZE];
+  static int altLen[MAX_BATCH_SIZE], offs[MAX_BATCH_SIZE];
+  const int w[4] = {W_MATCH, W_MISMATCH, W_OPEN, W_EXTEND};
+  if (!FalconSWFPGA_init((char*)"unused")) { printf("sw init failed\n"); return 1; }
+  for (int B = 1; B <= 128; B *= 2)                    // batch 1,2,4..128 as sw_host.cpp:240
+    for (int strategy = 0; strategy < 4; strategy++) {
+      char ref[MAX_SEQ_LENGTH]; int rl = 60 + (int)(rng() % 190);            // keeps min(len) <= 255 (this round's limit)
+      for (int k = 0; k < rl; k++) ref[k] = base();
+      for (int b = 0; b < B; b++) {                    // alt = ref prefix +-10 with 10 % substitutions (sw_host.cpp:160-180)
+        int al = rl - 11 + (int)(rng() % 22); if (al < 1) al = 1; if (al > 255) al = 255;
+        altLen[b] = al;
+        for (int k = 0; k < al; k++) alts[b][k] = (k < rl && rng() % 10) ? ref[k] : base();
+      }
+      double ns = FalconSWFPGA_run(ref, rl, alts, altLen, B, strategy, w[0], w[1], w[2], w[3], cig, offs, true);
+      if (ns < 0) { printf("sw: batch refused\n"); return 1; }
+      for (int b = 0; b < B; b++) if (cmp_cigar(cig[b], offs[b], ref, rl, alts[b], altLen[b], strategy, w)) { if (bad < 5) printf("sw B=%d s=%d b=%d mismatch\n", B, strategy, b); bad++; }
+      if (B <= 8) {                                    // the FPGA kernel's byte contract (FalconSW_FPGA.cpp:53-88)
+        std::vector<char> in(2 * B + 512 * (B + 1), 0);
+        for (int b = 0; b < B; b++) { in[2 * b] = (char)(altLen[b] & 0xff); in[2 * b + 1] = (char)(altLen[b] >> 8); memcpy(&in[2 * B + 512 + 512 * b], alts[b], altLen[b]); }
+        memcpy(&in[2 * B], ref, rl);
+        std::vector<short> out((2 * 512 + 2) * B + 2 + B);
+        _smithWatermanRun(in.data(), rl, B, strategy, w[0], w[1], w[2], w[3], out.data());
+        int ptr = B + 2;
+        for (int b = 0; b < B; b++) {
+          int num = out[b + 2];
+          ptr += 2 * num + 1;
+          if (num != cig[b].CigarElementNum || out[ptr - 1] != offs[b]) bad++;
+          for (int j = 0; j < num && j < cig[b].CigarElementNum; j++)
+            if (out[ptr - 3 - 2 * j] != cig[b].cigarElements[j].length || out[ptr - 2 - 2 * j] != cig[b].cigarElements[j].state) bad++;
+        }
+        if (((int)(unsigned short)out[0] | ((int)out[1] << 16)) != ptr) bad++;
+      }
+    }
+  FalconSWFPGA_release();
+  printf("htc-sw: %s\n", bad ? "FAILED" : "ok");
+  return bad;
+}
+
+int main() {
+  int bad = test_pairhmm() + test_sw();
+  cleanup();
+  return bad ? 1 : 0;
+}

@@ -59,3 +59,14 @@ def test_host_tables_match_golden():
         assert ph.tobytes() == g["ph2pr_" + tag].tobytes()
         assert m2m.tobytes() == g["m2m_head_" + tag].tobytes()
         assert init.tobytes() == g["init_" + tag].tobytes() and l10.tobytes() == g["log10_init_" + tag].tobytes()
+
+
+def test_compat_library_exports_reference_names():
+    """libaccg_compat.so carries the reference's own entry-point names (C++ linkage, so check the mangled table)."""
+    p = os.path.join(ROOT, "acc_genomics_amd", "libaccg_compat.so")
+    assert os.path.exists(p)
+    syms = os.popen("nm -DC %s" % p).read()
+    for name in ("compute_fpga(", "FalconPairHMM::computePairhmm(", "FalconSWFPGA_run(", "FalconSWFPGA_init(", "_smithWatermanRun(",
+                 "SWPairwiseAlignmentMultiBatch(", "serialize(void*, read_t const*, int)", "deserialize(void const*, hap_t*&)",
+                 "free_reads(", "cleanup()"):
+        assert name in syms, name
