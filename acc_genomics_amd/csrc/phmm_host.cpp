@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <numeric>
 #include "accg_internal.h"
@@ -102,7 +103,7 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K; uint32_t work0, n_work; int stream_cap; };
+struct KLaunch { int K; uint32_t work0, n_work; int stream_cap, haps_cap; };
 
 template <typename T>
 struct DevBuf {
@@ -135,6 +136,7 @@ struct accg_phmm_batch {
   std::vector<PhmmWork> work;
   std::vector<KLaunch> launches;
   uint64_t pairs = 0, cells = 0, algo_bytes = 0;
+  bool has_n = false;          // some haplotype contains an 'N': the dist table needs its fifth slab
   DevBuf<uint8_t> d_rblob, d_hblob;
   DevBuf<SeqRef> d_rd, d_hp;
   DevBuf<uint32_t> d_rd_out, d_hp_local, d_hap_ids;
@@ -166,7 +168,7 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
   }
   return n;
 }
-int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs) {
+int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, bool& has_n) {
   if (bytes < 4) return ACCG_ERR_BAD_WIRE;
   int32_t n; memcpy(&n, p, 4);
   if (n < 0) return ACCG_ERR_BAD_WIRE;
@@ -177,7 +179,10 @@ int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<Se
     if (len < 0 || pos + (size_t)len > bytes) return ACCG_ERR_BAD_WIRE;
     if (len == 0) return ACCG_ERR_EMPTY_SEQ;
     if (len > ACCG_PHMM_MAX_HAP) return ACCG_ERR_TOO_LONG;
-    for (int k = 0; k < len; k++) if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
+    for (int k = 0; k < len; k++) {
+      if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
+      has_n |= p[pos + k] == 'N';
+    }
     refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
     pos += (size_t)len;
   }
@@ -186,62 +191,127 @@ int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<Se
 
 inline int k_for(uint32_t read_len) { return (int)((read_len + 1 + 15) / 16); }   // one row reserved as "row 0"
 
+// Resident wavefronts per CU for the fp32 kernel at K rows per lane: LDS (160 KiB) and VGPR (512 per SIMD lane) limits.
+int waves_per_cu(int K, int nchar, int stream_cap, int haps_cap) {
+  const size_t lds = (phmm_lds_bytes(K, 4, nchar, stream_cap, haps_cap) + 511) / 512 * 512;
+  const int by_lds = (int)((160 * 1024) / lds);
+  const int vgpr = (13 * K + 16 + 7) / 8 * 8;              // measured: 13 K + 16 (kernel-resource-usage)
+  const int by_vgpr = std::min(8, 512 / vgpr) * 4;
+  return std::max(1, std::min(std::min(by_lds, by_vgpr), 32));
+}
+
+struct Chunk { uint32_t ids0, n; uint32_t stream_len; };
+
+// Greedy runs of haplotypes with at most `budget` stream entries (a single longer haplotype gets a run of its own).
+void chunk_region(const accg_phmm_batch& b, const Region& r, uint64_t budget, std::vector<std::pair<uint32_t, uint32_t>>& runs,
+                  std::vector<uint32_t>& lens) {
+  uint32_t h = 0;
+  while (h < r.n_haps) {
+    uint32_t h0 = h, n = 0;
+    uint64_t len = 1;   // terminal bubble
+    while (h < r.n_haps && n < (uint32_t)PHMM_HAPS_MAX) {
+      const uint64_t add = b.hp[r.hap0 + h].len + 1;
+      if (n > 0 && len + add > budget) break;
+      if (len + add > (uint64_t)PHMM_STREAM_MAX) break;   // ACCG_PHMM_MAX_HAP < PHMM_STREAM_MAX, so n == 0 never breaks here
+      len += add; n++; h++;
+    }
+    runs.push_back({h0, n});
+    lens.push_back((uint32_t)len);
+  }
+}
+
 // Cuts every region into jobs = (four reads of similar length) x (a run of haplotypes).
+// Single-wave workgroups are placed by the hardware dispatcher as slots free up, so the run length is
+// chosen to minimise the makespan of a longest-first list schedule on the resident-wave slots of the
+// chip (one prologue + 15-step fill per job against the quantisation of jobs over slots); e.g.
+// configs[1] comes out as 4096 jobs of 4 haplotypes = exactly one job per slot at 16 waves per CU.
 void partition(accg_phmm_batch& b) {
-  // how many wavefronts we would like in flight: enough for ~4 per SIMD on every CU
-  // Many short jobs: single-wave workgroups are placed by the hardware dispatcher, and with only a
-  // few long jobs per SIMD its placement (and the tail) costs up to 30 % (gpurun_out sweep);
-  // ~64 jobs per CU of >= 256 steps each measured best on configs[1].
-  uint64_t target_jobs = (uint64_t)std::max(b.ctx->n_cu, 1) * 64;
-  uint64_t min_steps = 256;   // below this the 15-step fill and the prologue start to show
-  if (const char* e = getenv("ACCG_PHMM_TARGET_JOBS")) target_jobs = strtoull(e, nullptr, 10);   // tuning knobs
-  if (const char* e = getenv("ACCG_PHMM_MIN_STEPS")) min_steps = strtoull(e, nullptr, 10);
-  struct Job { PhmmWork w; int K; uint64_t cost; int stream_len; };
-  std::vector<Job> jobs;
-  uint64_t total_quads = 0;
-  for (const Region& r : b.regions) total_quads += (r.n_reads + 3) / 4;
-  for (const Region& r : b.regions) {
+  const int nchar = b.has_n ? 5 : 4;
+  const int n_cu = std::max(b.ctx->n_cu, 1);
+  // quads per region, by descending read length so that the four reads of a wavefront need the same K
+  struct Quad { uint32_t read[4]; int K; };
+  std::vector<std::vector<Quad>> quads(b.regions.size());
+  uint64_t kw[PHMM_MAX_K + 1] = {0};
+  for (size_t ri = 0; ri < b.regions.size(); ri++) {
+    const Region& r = b.regions[ri];
     if (r.n_reads == 0 || r.n_haps == 0) continue;
-    // reads by descending length so that the four reads of a wavefront need the same K
     std::vector<uint32_t> order(r.n_reads);
     std::iota(order.begin(), order.end(), r.read0);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b.rd[x].len > b.rd[y].len; });
-    const uint32_t n_quads = (r.n_reads + 3) / 4;
-    // haplotype runs: capacity limits first, then split further while the chip is under-filled
-    uint64_t stream_total = 0;
-    for (uint32_t h = 0; h < r.n_haps; h++) stream_total += b.hp[r.hap0 + h].len + 1;
-    uint64_t want_chunks = (target_jobs + total_quads - 1) / std::max<uint64_t>(total_quads, 1);
-    uint64_t max_chunks_by_len = std::max<uint64_t>(1, stream_total / min_steps);
-    want_chunks = std::min<uint64_t>(std::min<uint64_t>(want_chunks, max_chunks_by_len), r.n_haps);
-    uint64_t budget = std::max<uint64_t>((stream_total + want_chunks - 1) / std::max<uint64_t>(want_chunks, 1), 1);
-    budget = std::min<uint64_t>(budget, PHMM_STREAM_MAX - 1);
-    struct Chunk { uint32_t ids0, n; uint64_t steps; };
-    std::vector<Chunk> chunks;
-    uint32_t h = 0;
-    while (h < r.n_haps) {
-      uint32_t ids0 = (uint32_t)b.hap_ids.size(), n = 0;
-      uint64_t len = 1;   // terminal bubble
-      while (h < r.n_haps && n < (uint32_t)PHMM_HAPS_MAX) {
-        uint64_t add = b.hp[r.hap0 + h].len + 1;
-        if (n > 0 && (len + add > budget)) break;          // budget is soft for a single long haplotype...
-        if (len + add > (uint64_t)PHMM_STREAM_MAX) break;  // ...the LDS stream is not (ACCG_PHMM_MAX_HAP < PHMM_STREAM_MAX)
-        b.hap_ids.push_back(r.hap0 + h);
-        len += add; n++; h++;
-      }
-      chunks.push_back({ids0, n, len + 15});
-    }
-    for (uint32_t q = 0; q < n_quads; q++) {
-      PhmmWork w;
-      uint32_t maxlen = 0; uint64_t rows = 0;
+    for (uint32_t q = 0; q < (r.n_reads + 3) / 4; q++) {
+      Quad Q; uint32_t maxlen = 0;
       for (int g = 0; g < PHMM_GROUPS; g++) {
-        uint32_t i = q * 4 + g;
-        w.read[g] = i < r.n_reads ? order[i] : PHMM_NO_READ;
-        if (i < r.n_reads) { maxlen = std::max(maxlen, b.rd[order[i]].len); rows += b.rd[order[i]].len; }
+        const uint32_t i = q * 4 + g;
+        Q.read[g] = i < r.n_reads ? order[i] : PHMM_NO_READ;
+        if (i < r.n_reads) maxlen = std::max(maxlen, b.rd[order[i]].len);
       }
+      Q.K = k_for(maxlen);
+      quads[ri].push_back(Q);
+      kw[Q.K] += (uint64_t)r.n_haps;
+    }
+  }
+  int K_dom = 1;
+  for (int k = 1; k <= PHMM_MAX_K; k++) if (kw[k] > kw[K_dom]) K_dom = k;
+
+  // candidate budgets: multiples of the most common haplotype length, plus a geometric ladder
+  std::vector<uint64_t> cand;
+  if (!b.hp.empty()) {
+    std::vector<uint32_t> lens; for (const SeqRef& h : b.hp) lens.push_back(h.len);
+    std::nth_element(lens.begin(), lens.begin() + lens.size() / 2, lens.end());
+    const uint64_t med = lens[lens.size() / 2] + 1;
+    for (uint64_t m = 1; m * med + 1 <= (uint64_t)PHMM_STREAM_MAX && m <= (uint64_t)PHMM_HAPS_MAX; m++) cand.push_back(m * med + 1);
+  }
+  for (uint64_t L = 256; L <= (uint64_t)PHMM_STREAM_MAX; L = L * 5 / 4) cand.push_back(L);
+  cand.push_back(PHMM_STREAM_MAX);
+  if (const char* e = getenv("ACCG_PHMM_STREAM_BUDGET")) { cand.clear(); cand.push_back(strtoull(e, nullptr, 10)); }   // tuning knob
+
+  const double prologue_steps = 30.0;   // table lookups + dist table + stream build, in units of one sweep step
+  uint64_t best_budget = cand[0];
+  double best_span = -1;
+  std::vector<double> costs;
+  for (uint64_t budget : cand) {
+    costs.clear();
+    uint32_t cap = 0;
+    for (size_t ri = 0; ri < b.regions.size(); ri++) {
+      if (quads[ri].empty()) continue;
+      std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
+      chunk_region(b, b.regions[ri], budget, runs, lens);
+      for (uint32_t len : lens) cap = std::max(cap, len);
+      for (const Quad& Q : quads[ri])
+        for (uint32_t len : lens) costs.push_back((len + 15 + prologue_steps) * (8.0 * Q.K + 10.0));
+    }
+    if (costs.empty()) break;
+    const int slots = n_cu * waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), PHMM_HAPS_MAX);
+    std::sort(costs.begin(), costs.end(), std::greater<double>());
+    std::vector<double> heap((size_t)slots, 0.0);          // min-heap of slot loads
+    auto cmp = std::greater<double>();
+    for (double c : costs) { std::pop_heap(heap.begin(), heap.end(), cmp); heap.back() += c; std::push_heap(heap.begin(), heap.end(), cmp); }
+    double span = *std::max_element(heap.begin(), heap.end());
+    // more resident waves per SIMD issue VALU work faster (tools/ubench.hip: 1.35 / 1.25 / 1.16 ns per instruction at 2 / 3 / 4)
+    const int wpc = slots / n_cu;
+    span *= wpc >= 16 ? 1.0 : wpc >= 12 ? 1.08 : wpc >= 8 ? 1.16 : 1.4;
+    if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
+  }
+
+  struct Job { PhmmWork w; int K; uint64_t cost; uint32_t stream_len; };
+  std::vector<Job> jobs;
+  for (size_t ri = 0; ri < b.regions.size(); ri++) {
+    if (quads[ri].empty()) continue;
+    const Region& r = b.regions[ri];
+    std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
+    chunk_region(b, r, best_budget, runs, lens);
+    std::vector<uint32_t> ids0;
+    for (auto& run : runs) {
+      ids0.push_back((uint32_t)b.hap_ids.size());
+      for (uint32_t k = 0; k < run.second; k++) b.hap_ids.push_back(r.hap0 + run.first + k);
+    }
+    for (const Quad& Q : quads[ri]) {
+      PhmmWork w;
+      for (int g = 0; g < PHMM_GROUPS; g++) w.read[g] = Q.read[g];
       w.pad_[0] = w.pad_[1] = 0;
-      for (const Chunk& c : chunks) {
-        w.hap_off = c.ids0; w.n_haps = c.n;
-        jobs.push_back({w, k_for(maxlen), c.steps * (uint64_t)k_for(maxlen), (int)(c.steps - 15)});
+      for (size_t c = 0; c < runs.size(); c++) {
+        w.hap_off = ids0[c]; w.n_haps = runs[c].second;
+        jobs.push_back({w, Q.K, (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
       }
     }
   }
@@ -250,9 +320,11 @@ void partition(accg_phmm_batch& b) {
   b.work.resize(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     b.work[i] = jobs[i].w;
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K) b.launches.push_back({jobs[i].K, (uint32_t)i, 0, 0});
-    b.launches.back().n_work++;
-    b.launches.back().stream_cap = std::max(b.launches.back().stream_cap, (jobs[i].stream_len + 63) / 64 * 64);
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K) b.launches.push_back({jobs[i].K, (uint32_t)i, 0, 0, 0});
+    KLaunch& L = b.launches.back();
+    L.n_work++;
+    L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
+    L.haps_cap = std::max(L.haps_cap, (int)jobs[i].w.n_haps);
   }
 }
 
@@ -262,18 +334,25 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   a.rblob = b.d_rblob.p; a.hblob = b.d_hblob.p; a.rd = b.d_rd.p; a.rd_out = b.d_rd_out.p; a.hp = b.d_hp.p;
   a.hp_local = b.d_hp_local.p; a.hap_ids = b.d_hap_ids.p; a.work = b.d_work.p; a.out = out;
   a.raw = b.d_out.p; a.n_rescued = b.d_nresc.p; a.tab = tab;
+  a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0;
   return a;
 }
 
 int launch_f32(accg_phmm_batch* b, int mode) {
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
-  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f32(l.K, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, l.stream_cap, b->ctx->stream));
+  for (const KLaunch& l : b->launches) {
+    a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
+    ACCG_HIP(phmm_launch_f32(l.K, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, b->ctx->stream));
+  }
   return ACCG_OK;
 }
 int launch_rescue(accg_phmm_batch* b) {
   ACCG_HIP(hipMemsetAsync(b->d_nresc.p, 0, sizeof(unsigned long long), b->ctx->stream));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
-  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_rescue_f64(l.K, a, l.work0, l.n_work, l.stream_cap, b->ctx->stream));
+  for (const KLaunch& l : b->launches) {
+    a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
+    ACCG_HIP(phmm_launch_rescue_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+  }
   return ACCG_OK;
 }
 
@@ -297,7 +376,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
     int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd);
     if (nr < 0) return nr;
-    int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp);
+    int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp, b->has_n);
     if (nh < 0) return nh;
     r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;
     uint64_t rsum = 0, hsum = 0;
@@ -362,7 +441,10 @@ extern "C" int accg_phmm_batch_run_f64(accg_phmm_batch* b) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
-  for (const KLaunch& l : b->launches) ACCG_HIP(phmm_launch_f64(l.K, a, l.work0, l.n_work, l.stream_cap, b->ctx->stream));
+  for (const KLaunch& l : b->launches) {
+    a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
+    ACCG_HIP(phmm_launch_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+  }
   return ACCG_OK;
 }
 extern "C" int accg_phmm_batch_results_f64(accg_phmm_batch* b, double* out_raw64) {

@@ -76,7 +76,7 @@ struct Rows {
   T nMM, nGM, nMX, nXX;   // row-0 coefficients of the lane to the right (lane 15: nMX = nXX = 1, so x_out = M + X)
   T a_out, x_out;         // what this lane hands to the right at the next step
   T acc;                  // running sum of M+X of the last read row (meaningful in lane 15)
-  unsigned padmask;       // bit k set: local row k is a clone of row 0
+  int npad;               // local rows k < npad are clones of row 0 (they form a prefix of the lane's rows)
 };
 
 // dist values of one step for this lane's K rows: QT vector reads, slab offset `off` (bytes).
@@ -94,8 +94,8 @@ __device__ __forceinline__ void load_dist(const unsigned char* tab_lane, unsigne
 }
 
 // One column for every lane.  d[k] = dist of local row k against this lane's column.
-template <bool STRICT, bool BOUNDARY, typename T, int K>
-__device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K], bool rst, T y0) {
+template <bool STRICT, typename T, int K>
+__device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
   T a_in = row_shr1(s.a_out);
   T x_in = row_shr1(s.x_out);
   // pass 1: everything that reads the previous column's state
@@ -106,10 +106,6 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K], bool rst,
     T a = (k == 0) ? a_in : diag_term<STRICT>(s.M[k - 1], s.X[k - 1], s.Y[k - 1], s.pMM[k], s.pGM[k]);
     Mn[k] = d[k] * a;
     Yn[k] = mul_add2<STRICT>(s.M[k], s.pMY[k], s.Y[k], s.pXX[k]);
-    if (BOUNDARY) {   // this lane sits on a bubble: column 0 of a new haplotype
-      Mn[k] = rst ? T(0) : Mn[k];
-      Yn[k] = rst ? (((s.padmask >> k) & 1u) ? y0 : T(0)) : Yn[k];
-    }
   }
   // pass 2: the X chain runs down the rows of the *current* column
   T xk = x_in;
@@ -124,21 +120,24 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K], bool rst,
   s.acc = s.acc + s.x_out;   // lane 15: x_out == M + X of the last read row (baseline_impl.cpp:91)
 }
 
+// One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
+// would cap the fp64 rescue kernel's LDS).
 template <typename T, int K, bool STRICT, bool RESCUE>
-__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, int stream_cap) {
+__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr unsigned SLAB = QT * 1024;                 // bytes between two bases' tables
+  const uint32_t job = blockIdx.x;
   unsigned char* tab = smem;
-  uint16_t* stream = reinterpret_cast<uint16_t*>(smem + PHMM_NCHAR * SLAB);
-  T* y0s = reinterpret_cast<T*>(smem + PHMM_NCHAR * SLAB + (((size_t)(15 + stream_cap + 48) * 2 + 15) / 16) * 16);
-  uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + ((sizeof(T) * (PHMM_HAPS_MAX + 1) + 15) / 16) * 16);
-  uint32_t* bpos = hcol + PHMM_HAPS_MAX + 1;
+  T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
+  uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
+  uint32_t* bpos = hcol + a.haps_cap + 1;
+  uint8_t* stream = reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4);
 
   const int lane = threadIdx.x;
   const int g = lane >> 4, l = lane & 15;
   // (field-wise loads: indexing a by-value copy of the struct with g would put it in scratch)
-  const PhmmWork* wp = a.work + (work_base + blockIdx.x);
+  const PhmmWork* wp = a.work + (work_base + job);
   const int n_list = __builtin_amdgcn_readfirstlane((int)wp->n_haps);
   const uint32_t hap_off = __builtin_amdgcn_readfirstlane(wp->hap_off);
 
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       y0s[n_haps] = a.tab.init / (T)(int)hr.len;     // baseline_impl.cpp:63
       hcol[n_haps] = col;
     }
-    for (int i = lane; i < (int)hr.len; i += 64) stream[15 + pos + 1 + i] = (uint16_t)(char_index(a.hblob[hr.off + i]) * SLAB);
+    for (int i = lane; i < (int)hr.len; i += 64) stream[15 + pos + 1 + i] = (uint8_t)char_index(a.hblob[hr.off + i]);
     pos += (int)hr.len + 1;
     n_haps++;
   }
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   const int R = (int)rr.len;
   const int pad = 16 * K - R;               // >= 1 by construction of the job
   const uint8_t* rb = a.rblob + rr.off;
-  s.padmask = 0;
+  s.npad = pad - l * K;                     // clones are the first `pad` flat rows
   typedef typename Vec16<T>::type V;
 #pragma unroll
   for (int q = 0; q < QT; q++) {
@@ -214,13 +213,13 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
         } else {
           // clone of row 0: M stays 0 (dist = 0), X stays 0 (0*0 + 0*1), Y keeps INIT/H (0*0 + Y*1)
           s.pMM[k] = T(0); s.pGM[k] = T(0); s.pMX[k] = T(0); s.pXX[k] = T(1); s.pMY[k] = T(0);
-          s.padmask |= 1u << k;
         }
       }
     }
     // dist table: one 16-byte vector per (hap base, row quad, lane)
 #pragma unroll
-    for (int c = 0; c < PHMM_NCHAR; c++) {
+    for (int c = 0; c < 5; c++) {
+      if (c >= a.nchar) break;
       V v;
 #pragma unroll
       for (int e = 0; e < VN; e++)   // rs == hap || rs == 'N' || hap == 'N'   (baseline_impl.cpp:80)
@@ -241,61 +240,69 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's LDS writes (table, stream) before its own reads
+  __builtin_amdgcn_wave_barrier();
 
   // ---- sweep ----------------------------------------------------------------------------------
-  const uint16_t* hs = stream + 15 - l;               // hs[t] = this lane's column at step t
+  const uint8_t* hs = stream + 15 - l;                // hs[t] = this lane's column at step t (base index 0..4)
   const unsigned char* tab_lane = tab + lane * 16;
   int t = 0, jn = 0, jl = -1;
   int nb = 0;                 // stream position of the next bubble lane 0 will meet
   unsigned rm = 0;            // bit i: lane i of every row is on a bubble this step
   T dn[K];                    // dist of step t   (loaded one step ahead)
-  load_dist<T, K>(tab_lane, hs[0], dn);
-  unsigned o1 = hs[1];        // slab offset of step t+1 (loaded two steps ahead)
+  load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
+  unsigned o1 = hs[1];        // base index of step t+1 (loaded two steps ahead)
   constexpr int U = 4;
   while (t < t_end) {
-    if (rm == 0 && nb - t >= U) {
+    if (rm == 0 && nb - t >= U) {          // no lane is on a bubble for the next U steps
 #pragma unroll
       for (int u = 0; u < U; u++) {
         T d[K];
 #pragma unroll
         for (int k = 0; k < K; k++) d[k] = dn[k];
-        load_dist<T, K>(tab_lane, o1, dn);
+        load_dist<T, K>(tab_lane, o1 * SLAB, dn);
         o1 = hs[t + u + 2];
-        column<STRICT, false>(s, d, false, T(0));
+        column<STRICT>(s, d);
       }
       t += U;
       continue;
     }
     const bool nbit = (t == nb);
-    rm = ((rm << 1) | (nbit ? 1u : 0u)) & 0xFFFFu;
     if (nbit) { jn++; nb = __builtin_amdgcn_readfirstlane((int)bpos[jn]); }
-    const bool rst = (rm >> l) & 1u;
-    T y0 = T(0);
-    if (rst) {
-      if (l == 15 && jl >= 0 && have) a.out[out_base + hcol[jl]] = s.acc;   // haplotype jl is complete
-      jl++;
-      y0 = y0s[jl];
-      s.acc = T(0);
-    }
+    rm = ((rm << 1) | (nbit ? 1u : 0u)) & 0xFFFFu;
     T d[K];
 #pragma unroll
     for (int k = 0; k < K; k++) d[k] = dn[k];
-    load_dist<T, K>(tab_lane, o1, dn);
+    load_dist<T, K>(tab_lane, o1 * SLAB, dn);
     o1 = hs[t + 2];
-    column<STRICT, true>(s, d, rst, y0);
+    if (rm == 0) { column<STRICT>(s, d); t++; continue; }     // the last few columns in front of a bubble
+    // Some lane (one per row of 16) is on a bubble = column 0 of its next haplotype.  Everybody runs the
+    // ordinary column; that lane then overwrites its state with the column-0 border
+    // (M = X = 0, Y = 0, clones of row 0: Y = INIT/H; baseline_impl.cpp:60-70) under EXEC.
+    const bool rst = (rm >> l) & 1u;
+    T acc_done = s.acc;
+    column<STRICT>(s, d);
+    if (rst) {
+      if (l == 15 && jl >= 0 && have) a.out[out_base + hcol[jl]] = acc_done;   // haplotype jl is complete
+      jl++;
+      const T y0 = y0s[jl];
+#pragma unroll
+      for (int k = 0; k < K; k++) { s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = (k < s.npad) ? y0 : T(0); }
+      s.x_out = T(0);
+      s.acc = T(0);
+    }
     t++;
   }
 }
 
 template <typename T, bool STRICT, bool RESCUE>
-hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, int stream_cap, hipStream_t st) {
+hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
   if (n_work == 0) return hipSuccess;
   dim3 grid(n_work), block(64);
 #define ACCG_CASE(KK)                                                                                         \
   case KK: {                                                                                                  \
-    const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), stream_cap);                                        \
-    hipLaunchKernelGGL((phmm_kernel<T, KK, STRICT, RESCUE>), grid, block, lds, st, a, work_base, stream_cap); \
+    const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap);                 \
+    hipLaunchKernelGGL((phmm_kernel<T, KK, STRICT, RESCUE>), grid, block, lds, st, a, work_base);             \
   } break;
   switch (K) {
     ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
@@ -308,14 +315,14 @@ hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_wo
 
 }  // namespace
 
-hipError_t phmm_launch_f32(int K, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
-  return strict ? launch<float, true, false>(K, a, wb, n, cap, s) : launch<float, false, false>(K, a, wb, n, cap, s);
+hipError_t phmm_launch_f32(int K, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return strict ? launch<float, true, false>(K, a, wb, n, s) : launch<float, false, false>(K, a, wb, n, s);
 }
-hipError_t phmm_launch_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
-  return launch<double, true, false>(K, a, wb, n, cap, s);
+hipError_t phmm_launch_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return launch<double, true, false>(K, a, wb, n, s);
 }
-hipError_t phmm_launch_rescue_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, int cap, hipStream_t s) {
-  return launch<double, true, true>(K, a, wb, n, cap, s);
+hipError_t phmm_launch_rescue_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return launch<double, true, true>(K, a, wb, n, s);
 }
 
 }  // namespace accg
