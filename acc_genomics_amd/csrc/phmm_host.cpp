@@ -290,6 +290,9 @@ void partition(accg_phmm_batch& b) {
     // more resident waves per SIMD issue VALU work faster (tools/ubench.hip: 1.35 / 1.25 / 1.16 ns per instruction at 2 / 3 / 4)
     const int wpc = slots / n_cu;
     span *= wpc >= 16 ? 1.0 : wpc >= 12 ? 1.08 : wpc >= 8 ? 1.16 : 1.4;
+    // the hardware dispatcher is not an ideal list scheduler: with about one job per slot it measured ~6 % behind
+    // two or four per slot on configs[1] (gpurun sweep)
+    span *= 1.0 + 0.10 * (double)slots / (double)costs.size();
     if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
   }
 

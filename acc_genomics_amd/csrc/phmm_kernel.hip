@@ -53,11 +53,13 @@ __device__ __forceinline__ double row_shr1(double v) {
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// diagonal term handed to the row below:  M*pMM + (X + Y)*pGM
+// diagonal term handed to the row below:  M*pMM + X*pGM + Y*pGM.
+// Fast mode keeps Y pre-multiplied by the consumer row's pGM (Yt = Y*pGM', updated with the coefficient
+// pMY*pGM' that is folded into a register once per job), which makes the term two fmas.
 template <bool STRICT, typename T>
 __device__ __forceinline__ T diag_term(T m, T x, T y, T pmm, T pgm) {
   if (STRICT) { T a = m * pmm + x * pgm; return a + y * pgm; }   // baseline_impl.cpp:84 order
-  return fma_(m, pmm, (x + y) * pgm);
+  return fma_(m, pmm, fma_(x, pgm, y));
 }
 template <bool STRICT, typename T>
 __device__ __forceinline__ T mul_add2(T a, T b, T c, T d) {      // a*b + c*d
@@ -71,8 +73,8 @@ template <> struct Vec16<double> { typedef double type __attribute__((ext_vector
 
 template <typename T, int K>
 struct Rows {
-  T M[K], X[K], Y[K];
-  T pMM[K], pGM[K], pMX[K], pXX[K], pMY[K];
+  T M[K], X[K], Y[K];     // fast mode: Y[k] holds Y * (pGM of the row below)
+  T pMM[K], pGM[K], pMX[K], pXX[K], pMY[K];   // fast mode: pMY[k] holds pMY * (pGM of the row below)
   T nMM, nGM, nMX, nXX;   // row-0 coefficients of the lane to the right (lane 15: nMX = nXX = 1, so x_out = M + X)
   T a_out, x_out;         // what this lane hands to the right at the next step
   T acc;                  // running sum of M+X of the last read row (meaningful in lane 15)
@@ -239,6 +241,10 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     } else if (l == 15) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
     else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
+  if (!STRICT) {
+#pragma unroll
+    for (int k = 0; k < K; k++) s.pMY[k] = s.pMY[k] * (k + 1 < K ? s.pGM[k + 1] : s.nGM);
+  }
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's LDS writes (table, stream) before its own reads
   __builtin_amdgcn_wave_barrier();
@@ -287,7 +293,11 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       jl++;
       const T y0 = y0s[jl];
 #pragma unroll
-      for (int k = 0; k < K; k++) { s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = (k < s.npad) ? y0 : T(0); }
+      for (int k = 0; k < K; k++) {
+        s.M[k] = T(0); s.X[k] = T(0);
+        const T yk = STRICT ? y0 : y0 * (k + 1 < K ? s.pGM[k + 1] : s.nGM);
+        s.Y[k] = (k < s.npad) ? yk : T(0);
+      }
       s.x_out = T(0);
       s.acc = T(0);
     }

@@ -141,9 +141,11 @@ double orc_phmm_forward_f64(int rslen, int haplen, const char* rs, const char* q
   FTZ_BEGIN; double r = fwd_d(rslen, haplen, rs, q, qi, qd, qc, hap, sum_order); FTZ_END; return r;
 }
 
-/* Same recurrence with the contraction the GPU fast mode uses (one rounding per fma):
- *   a  = fma(Mp, pMM, (Xp + Yp) * pGM);  M = dist * a
- *   X  = fma(Mup, pMX, Xup * pXX);       Y = fma(Mleft, pMY, Yleft * pYY)
+/* Same recurrence in the arithmetic of the GPU fast mode (one rounding per fma); Yt = Y * pGM[r+1] is
+ * what the kernel keeps per row, so that the diagonal term is two fmas:
+ *   M[r][c]  = dist * fma(M[r-1][c-1], pMM[r], fma(X[r-1][c-1], pGM[r], Yt[r-1][c-1]))
+ *   X[r][c]  = fma(M[r-1][c], pMX[r], X[r-1][c] * pXX[r])
+ *   Yt[r][c] = fma(M[r][c-1], pMY[r]*pGM[r+1], Yt[r][c-1] * pXX[r])        (pGM[R+1] := 0, Yt[0][c] = (INIT/H)*pGM[1])
  * and the scalar summation order.  Not a reference function: it exists so that tests can separate
  * "GPU differs from its own arithmetic model" (a bug) from "model differs from the reference by
  * rounding" (bounded, checked against the 1e-5 budget). */
@@ -154,21 +156,23 @@ float orc_phmm_forward_f32_fma(int rslen, int haplen, const char* rs, const char
   int R = rslen, H = haplen;
   float* buf = (float*)malloc(sizeof(float) * 6 * (size_t)(H + 1));
   float *Mp = buf, *Xp = Mp + H + 1, *Yp = Xp + H + 1, *Mc = Yp + H + 1, *Xc = Mc + H + 1, *Yc = Xc + H + 1;
-  for (int c = 0; c <= H; c++) { Mp[c] = 0.f; Xp[c] = 0.f; Yp[c] = g_init_f / (float)H; }
+  float g1 = 1.0f - g_ph_f[qc[0] & 127];
+  for (int c = 0; c <= H; c++) { Mp[c] = 0.f; Xp[c] = 0.f; Yp[c] = (g_init_f / (float)H) * g1; }
   for (int r = 1; r <= R; r++) {
     int qi_ = qi[r - 1] & 127, qd_ = qd[r - 1] & 127, qc_ = qc[r - 1] & 127, qq_ = q[r - 1] & 127;
-    float pMM = g_m2m_f[tri(qi_, qd_)], pGM = 1.0f - g_ph_f[qc_], pMX = g_ph_f[qi_], pXX = g_ph_f[qc_],
-          pMY = g_ph_f[qd_], pYY = g_ph_f[qc_];
+    float pMM = g_m2m_f[tri(qi_, qd_)], pGM = 1.0f - g_ph_f[qc_], pMX = g_ph_f[qi_], pXX = g_ph_f[qc_], pMY = g_ph_f[qd_];
+    float gnext = r < R ? 1.0f - g_ph_f[qc[r] & 127] : 0.0f;
+    float pMYg = pMY * gnext;
     float dmis = g_ph_f[qq_] / 3.0f, dmat = 1.0f - g_ph_f[qq_];
     char rb = rs[r - 1];
     Mc[0] = 0.f; Xc[0] = 0.f; Yc[0] = 0.f;
     for (int c = 1; c <= H; c++) {
       char hb = hap[c - 1];
       float dist = (rb == hb || rb == 'N' || hb == 'N') ? dmat : dmis;
-      float a = fmaf(Mp[c - 1], pMM, (Xp[c - 1] + Yp[c - 1]) * pGM);
+      float a = fmaf(Mp[c - 1], pMM, fmaf(Xp[c - 1], pGM, Yp[c - 1]));
       Mc[c] = dist * a;
       Xc[c] = fmaf(Mp[c], pMX, Xp[c] * pXX);
-      Yc[c] = fmaf(Mc[c - 1], pMY, Yc[c - 1] * pYY);
+      Yc[c] = fmaf(Mc[c - 1], pMYg, Yc[c - 1] * pXX);
     }
     float* t;
     t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Yp; Yp = Yc; Yc = t;
