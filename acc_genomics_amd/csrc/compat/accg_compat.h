@@ -80,8 +80,8 @@ struct CigarElement { int length; int state; };
 struct Cigar { struct CigarElement cigarElements[MAX_SEQ_LENGTH]; int CigarElementNum; };
 
 bool FalconSWFPGA_init(char* bitstream);
-// Returns device time in ns.  Results in place; sequences the device cannot take (min length > 255)
-// make it return -1 with nothing written (the reference falls back to its AVX code at this point).
+// Returns device time in ns.  Results in place; a batch the device cannot take (length 0 or > 1535)
+// makes it return -1 with nothing written (the reference falls back to its AVX code at this point).
 double FalconSWFPGA_run(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int* altLengths, int batchSize,
                         int overhang_strategy, int w_match, int w_mismatch, int w_open, int w_extend,
                         struct Cigar* cigarResults, int* alignmentOffsets, bool isFPGA);

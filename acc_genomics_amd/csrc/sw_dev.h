@@ -5,11 +5,9 @@
 
 namespace accg {
 
-constexpr int SW_MAX_K = 16;             // lane-sequence positions per lane
-constexpr int SW_MAX_LANE_SEQ = 16 * SW_MAX_K - 1;   // 255 (one position reserved for the border)
 constexpr uint32_t SW_NO_PAIR = 0xFFFFFFFFu;
 
-// One wavefront's job: four groups (DPP rows) x two packed pairs (lo/hi 16-bit halves).
+// One wavefront's job: 64/lpp groups of lpp lanes x two packed pairs (lo/hi 16-bit halves).
 struct SwWork {
   uint32_t pair[8];     // pair[2*g + half]; SW_NO_PAIR = empty (hi empty: int32 mode or no partner)
 };
@@ -35,12 +33,14 @@ struct SwArgs {
 // pack16: two pairs per group in 16-bit halves (scores must fit int16), else one pair per group in int32.
 // with_bt: also record the per-cell decisions needed by the backtrace (a.bt); job i of the launch uses
 // a.bt + (i - bt_first) * a.bt_item_stride.
-hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
+// lpp = lanes per pair group: 16 (lane sequence <= 255), 32 (<= 511) or 64 (<= 1535).
+hipError_t sw_launch(int K, int lpp, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
                      uint32_t bt_first, int sweep_cap, hipStream_t s);
+int sw_pick_k(int lane_seq_len, int lpp);
 // the backtrace proper (calculateCigarOneBatch, FalconSW_AVX.cpp:2303-2419): one thread per pair
-hipError_t sw_trace_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
+hipError_t sw_trace_launch(int K, int lpp, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
                            uint32_t bt_first, int sweep_cap, hipStream_t s);
 size_t sw_lds_bytes(int sweep_cap);
-inline uint64_t sw_bt_item_uint4(int sweep_cap) { return (uint64_t)4 * (sweep_cap + 16) * 16; }
+inline uint64_t sw_bt_item_uint4(int sweep_cap, int lpp) { return (uint64_t)64 * (sweep_cap + lpp); }
 
 }  // namespace accg

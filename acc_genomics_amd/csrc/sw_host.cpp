@@ -13,7 +13,7 @@
 using namespace accg;
 
 namespace {
-struct SwLaunch { int K; bool pack16, lane_is_alt; uint32_t work0, n_work; int sweep_cap; };
+struct SwLaunch { int K, lpp; bool pack16, lane_is_alt; uint32_t work0, n_work; int sweep_cap; };
 template <typename T> int dev_upload(T** dst, const void* src, size_t bytes, hipStream_t s) {
   ACCG_HIP(hipMalloc((void**)dst, bytes ? bytes : 16));
   if (bytes) ACCG_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
@@ -46,13 +46,13 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   ACCG_HIP(hipSetDevice(ctx->device));
   std::unique_ptr<accg_sw_batch> b(new accg_sw_batch);
   b->ctx = ctx; b->n = n;
-  struct Item { uint32_t idx; int K, ns; bool p16, lia; };
+  struct Item { uint32_t idx; int K, lpp, ns; bool p16, lia; };
   std::vector<Item> items(n);
   int max_rl = 0, max_al = 0;
   for (int k = 0; k < n; k++) {
     const int rl = ref_lens[k], al = alt_lens[k];
     if (rl <= 0 || al <= 0) return ACCG_ERR_EMPTY_SEQ;
-    if (rl > ACCG_SW_MAX_LEN || al > ACCG_SW_MAX_LEN || std::min(rl, al) > ACCG_SW_MAX_SHORT) return ACCG_ERR_TOO_LONG;
+    if (rl > ACCG_SW_MAX_LEN || al > ACCG_SW_MAX_LEN) return ACCG_ERR_TOO_LONG;
     if (strategies && strategies[k] > 3) return ACCG_ERR_BAD_ARG;
     max_rl = std::max(max_rl, rl); max_al = std::max(max_al, al);
     const bool lia = al <= rl;                       // lanes hold the shorter sequence
@@ -62,7 +62,8 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
     const long hi = (long)std::max(w_match, 0) * nl;
     const long lo = (long)std::min(w_open, 0) * 2 + (long)std::min(w_extend, 0) * ns + (long)std::min(w_mismatch, 0) * nl;
     const bool p16 = hi <= 32000 && lo >= -32000 && std::abs(w_match) < 16000 && std::abs(w_mismatch) < 16000;
-    items[k] = {(uint32_t)k, (nl + 1 + 15) / 16, ns, p16, lia};
+    const int lpp = nl <= 255 ? 16 : nl <= 511 ? 32 : 64;
+    items[k] = {(uint32_t)k, sw_pick_k(nl, lpp), lpp, ns, p16, lia};
     b->cells += (uint64_t)rl * al;
     b->algo_bytes += (uint64_t)rl + al + 16;
   }
@@ -70,6 +71,7 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
     if (x.lia != y.lia) return x.lia > y.lia;
     if (x.p16 != y.p16) return x.p16 > y.p16;
+    if (x.lpp != y.lpp) return x.lpp < y.lpp;
     if (x.K != y.K) return x.K > y.K;
     return x.ns > y.ns;
   });
@@ -78,20 +80,22 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   size_t i = 0;
   while (i < items.size()) {
     const Item& first = items[i];
-    SwLaunch L{first.K, first.p16, first.lia, (uint32_t)work.size(), 0, 0};
+    SwLaunch L{first.K, first.lpp, first.p16, first.lia, (uint32_t)work.size(), 0, 0};
+    const int gpw = 64 / first.lpp;   // groups per wavefront
     std::vector<std::pair<uint32_t, uint32_t>> groups;
-    while (i < items.size() && items[i].K == first.K && items[i].p16 == first.p16 && items[i].lia == first.lia) {
+    while (i < items.size() && items[i].K == first.K && items[i].lpp == first.lpp && items[i].p16 == first.p16 && items[i].lia == first.lia) {
       L.sweep_cap = std::max(L.sweep_cap, items[i].ns);
-      if (first.p16 && i + 1 < items.size() && items[i + 1].K == first.K && items[i + 1].p16 && items[i + 1].lia == first.lia &&
+      if (first.p16 && i + 1 < items.size() && items[i + 1].K == first.K && items[i + 1].lpp == first.lpp && items[i + 1].p16 && items[i + 1].lia == first.lia &&
           items[i + 1].ns == items[i].ns) {
         groups.push_back({items[i].idx, items[i + 1].idx}); i += 2;
       } else { groups.push_back({items[i].idx, SW_NO_PAIR}); i += 1; }
     }
-    for (size_t gI = 0; gI < groups.size(); gI += 4) {
+    for (size_t gI = 0; gI < groups.size(); gI += gpw) {
       SwWork w;
       for (int g = 0; g < 4; g++) {
-        w.pair[2 * g] = gI + g < groups.size() ? groups[gI + g].first : SW_NO_PAIR;
-        w.pair[2 * g + 1] = gI + g < groups.size() ? groups[gI + g].second : SW_NO_PAIR;
+        const bool on = g < gpw && gI + g < groups.size();
+        w.pair[2 * g] = on ? groups[gI + g].first : SW_NO_PAIR;
+        w.pair[2 * g + 1] = on ? groups[gI + g].second : SW_NO_PAIR;
       }
       work.push_back(w);
     }
@@ -129,7 +133,7 @@ extern "C" int accg_sw_batch_run(accg_sw_batch* b) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   for (const SwLaunch& l : b->launches)
-    ACCG_HIP(sw_launch(l.K, l.pack16, l.lane_is_alt, false, b->args, l.work0, l.n_work, l.work0, l.sweep_cap, b->ctx->stream));
+    ACCG_HIP(sw_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, false, b->args, l.work0, l.n_work, l.work0, l.sweep_cap, b->ctx->stream));
   return ACCG_OK;
 }
 
@@ -154,7 +158,7 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   // size the scratch for the largest slice any launch will use
   uint64_t need = 0;
   for (const SwLaunch& l : b->launches) {
-    const uint64_t per = sw_bt_item_uint4(l.sweep_cap) * sizeof(uint4);
+    const uint64_t per = sw_bt_item_uint4(l.sweep_cap, l.lpp) * sizeof(uint4);
     const uint64_t items = std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, limit / per));
     need = std::max(need, items * per);
   }
@@ -168,13 +172,13 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   SwArgs a = b->args;
   a.bt = b->d_bt; a.cig_n = b->d_cig_n; a.cig_off = b->d_cig_off; a.cig_el = b->d_cig_el; a.max_el = max_el;
   for (const SwLaunch& l : b->launches) {
-    a.bt_item_stride = sw_bt_item_uint4(l.sweep_cap);
+    a.bt_item_stride = sw_bt_item_uint4(l.sweep_cap, l.lpp);
     const uint64_t per = a.bt_item_stride * sizeof(uint4);
     const uint32_t slice = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, b->bt_bytes / per));
     for (uint32_t off = 0; off < l.n_work; off += slice) {
       const uint32_t n = std::min(slice, l.n_work - off), w0 = l.work0 + off;
-      ACCG_HIP(sw_launch(l.K, l.pack16, l.lane_is_alt, true, a, w0, n, w0, l.sweep_cap, s));
-      ACCG_HIP(sw_trace_launch(l.K, l.pack16, l.lane_is_alt, a, w0, n, w0, l.sweep_cap, s));
+      ACCG_HIP(sw_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, true, a, w0, n, w0, l.sweep_cap, s));
+      ACCG_HIP(sw_trace_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, a, w0, n, w0, l.sweep_cap, s));
     }
   }
   return ACCG_OK;

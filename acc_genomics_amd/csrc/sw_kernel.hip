@@ -74,9 +74,13 @@ template <> struct Val<false> {
   enum { NEG = NEG32 };
 };
 
-template <int OLD>
-__device__ __forceinline__ int row_shr1_old(int v) {   // lane 0 of every row receives OLD
-  return __builtin_amdgcn_update_dpp(OLD, v, 0x111, 0xF, 0xF, false);
+// lane l <- lane l-1 inside a group of LPP lanes; the first lane of every group receives OLD.
+// 16 lanes = one DPP row (row_shr:1); 32/64 lanes: wave_shr:1 plus one select for lane 32.
+template <int OLD, int LPP>
+__device__ __forceinline__ int group_shr1_old(int v, bool leader) {
+  if (LPP == 16) return __builtin_amdgcn_update_dpp(OLD, v, 0x111, 0xF, 0xF, false);
+  const int r = __builtin_amdgcn_update_dpp(OLD, v, 0x138, 0xF, 0xF, false);
+  return (LPP == 32 && leader) ? OLD : r;
 }
 
 __device__ __forceinline__ int iabs(int x) { return x < 0 ? -x : x; }
@@ -88,10 +92,11 @@ __device__ __forceinline__ unsigned long long cand_key(int score, int dist, int 
   return ((unsigned long long)(unsigned)(score + 0x40000000) << 24) | ((unsigned long long)(4095 - dist) << 12) |
          (unsigned long long)(4095 - order);
 }
-__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {   // max over the 16 lanes of a row
+template <int LPP>
+__device__ __forceinline__ unsigned long long group_max_u64(unsigned long long v) {   // max over the LPP lanes of a group
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
-    unsigned lo = __shfl_xor((unsigned)v, m, 16), hi = __shfl_xor((unsigned)(v >> 32), m, 16);
+  for (int m = 1; m < LPP; m <<= 1) {
+    unsigned lo = __shfl_xor((unsigned)v, m, LPP), hi = __shfl_xor((unsigned)(v >> 32), m, LPP);
     unsigned long long o = ((unsigned long long)hi << 32) | lo;
     v = o > v ? o : v;
   }
@@ -105,18 +110,19 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
 //   z: cell is NOT diagonal            (diag >= down && diag >= right fails, :1798)
 //   w: DOWN wins over RIGHT            (right >= down fails, :1803)
 // With the planes, btrack's +-k (:1805-1809) is the run length of not-opened cells walked by sw_trace.
-template <int K, bool P16, bool LANE_IS_ALT, bool BT>
+template <int K, int LPP, bool P16, bool LANE_IS_ALT, bool BT>
 __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, uint32_t bt_first, int sweep_cap) {
   typedef Val<P16> VT;
   typedef typename VT::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per group: sweep characters (two pairs packed lo|hi<<16) and the log of the last lane position
-  uint32_t* sweep_ch = reinterpret_cast<uint32_t*>(smem);                 // [4][sweep_cap + 1]
+  uint32_t* sweep_ch = reinterpret_cast<uint32_t*>(smem);                 // [4][sweep_cap + 1] (NG <= 4 used)
   int32_t* edge_log = reinterpret_cast<int32_t*>(smem) + 4 * (sweep_cap + 1);   // [4][sweep_cap + 1] (bits of T)
 
-  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  constexpr int NG = 64 / LPP;                 // pair groups per wavefront
+  const int lane = threadIdx.x, g = lane / LPP, l = lane % LPP;
   const SwWork* wp = a.work + (work_base + blockIdx.x);
-  const uint32_t pr[2] = {wp->pair[2 * g], P16 ? wp->pair[2 * g + 1] : SW_NO_PAIR};
+  const uint32_t pr[2] = {g < NG ? wp->pair[2 * g] : SW_NO_PAIR, (P16 && g < NG) ? wp->pair[2 * g + 1] : SW_NO_PAIR};
   const bool have[2] = {pr[0] != SW_NO_PAIR, pr[1] != SW_NO_PAIR};
 
   int nl[2] = {0, 0}, ns = 0, prefill[2] = {0, 0}, strat[2] = {0, 0};
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   // ---- sweep characters into LDS -----------------------------------------------------------------
   uint32_t* my_ch = sweep_ch + g * (sweep_cap + 1);
   int32_t* my_log = edge_log + g * (sweep_cap + 1);
-  for (int i = l; i < ns; i += 16) {
+  for (int i = l; i < ns; i += LPP) {
     uint32_t c0 = have[0] ? sseq[0][i] : 0u, c1 = have[1] ? sseq[1][i] : 0u;
     my_ch[i + 1] = c0 | (c1 << 16);
   }
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
     int c_[2], wm_[2], wd_[2], op_[2], h_[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const int pad = 16 * K - nl[h];
+      const int pad = LPP * K - nl[h];
       const int p = l * K + k - pad + 1;       // 1-based position, <= 0: border clone
       if (have[h] && p >= 1) {
         c_[h] = lseq[h][p - 1]; wm_[h] = W_M; wd_[h] = W_X - W_M; op_[h] = W_O;
@@ -173,9 +179,9 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   T h_last = Hp[K - 1], f_last = VT::splat(NEG);
   // what the border clone in front of lane 0 hands over: H[i][0] along the sweep
   // (lane 0, k = 0 is always a clone, so only its *inputs* matter: 0 / NEG below)
-  int t_end = ns + 15;
+  int t_end = ns + LPP - 1;
 #pragma unroll
-  for (int m = 16; m < 64; m <<= 1) { int o = __shfl_xor(t_end, m); t_end = o > t_end ? o : t_end; }
+  for (int m = LPP; m < 64; m <<= 1) { int o = __shfl_xor(t_end, m); t_end = o > t_end ? o : t_end; }
   t_end = __builtin_amdgcn_readfirstlane(t_end);
   __syncthreads();
 
@@ -183,8 +189,9 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   for (int t = 1; t <= t_end; t++) {
     // hand-off from the lane on the left (all lanes, also the switched-off ones: their registers are frozen)
     d_in = h_in;
-    h_in = VT::from_bits(row_shr1_old<0>(VT::bits(h_last)));
-    f_in = VT::from_bits(P16 ? row_shr1_old<(int)0x80008000>(VT::bits(f_last)) : row_shr1_old<NEG32>(VT::bits(f_last)));
+    h_in = VT::from_bits(group_shr1_old<0, LPP>(VT::bits(h_last), l == 0));
+    f_in = VT::from_bits(P16 ? group_shr1_old<(int)0x80008000, LPP>(VT::bits(f_last), l == 0)
+                             : group_shr1_old<NEG32, LPP>(VT::bits(f_last), l == 0));
     const int i = t - l;                       // this lane's sweep index
     if (i >= 1 && i <= ns) {
       const T c = VT::from_bits((int)my_ch[i]);
@@ -209,9 +216,9 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
         hdiag = hold; hup = hn; Hp[k] = hn;
       }
       h_last = hup; f_last = f;
-      if (BT) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + 16) + t) * 16 + l] =
+      if (BT) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + LPP) + t) * LPP + l] =
           make_uint4(pf, pg, pn, pd);
-      if (l == 15) my_log[i] = VT::bits(hup);
+      if (l == LPP - 1) my_log[i] = VT::bits(hup);
     }
   }
   __syncthreads();
@@ -224,11 +231,11 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   for (int h = 0; h < (P16 ? 2 : 1); h++) {
     if (!have[h]) continue;   // uniform per group of 16 lanes; shuffles below stay inside the group
     const int refLen = LANE_IS_ALT ? ns : nl[h], altLen = LANE_IS_ALT ? nl[h] : ns;
-    const int pad = 16 * K - nl[h];
+    const int pad = LPP * K - nl[h];
     // last column: ties -> larger i  (:2320-2326)
     unsigned long long ck = 0;
     if (LANE_IS_ALT) {
-      for (int s = l + 1; s <= ns; s += 16) {
+      for (int s = l + 1; s <= ns; s += LPP) {
         int v = VT::get(VT::from_bits(my_log[s]), h);
         unsigned long long key = ((unsigned long long)(unsigned)(v + 0x40000000) << 16) | (unsigned)s;
         ck = key > ck ? key : ck;
@@ -244,12 +251,12 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
         }
       }
     }
-    ck = row_max_u64(ck);
+    ck = group_max_u64<LPP>(ck);
     const int col_best = (int)(unsigned)(ck >> 16) - 0x40000000, col_i = (int)(ck & 0xFFFF);
     int p1, p2, best;
     if (strat[h] == 1) {            // INDEL: the corner
       p1 = refLen; p2 = altLen;
-      best = __shfl(VT::get(Hp[K - 1], h), (g << 4) | 15);
+      best = __shfl(VT::get(Hp[K - 1], h), g * LPP + LPP - 1);
     } else if (strat[h] == 2) {     // LEADING_INDEL: last column only
       p1 = col_i; p2 = altLen; best = col_best;
     } else {
@@ -261,12 +268,12 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
           if (j >= 1) { unsigned long long key = cand_key(VT::get(Hp[k], h), iabs(refLen - j), j); bk = key > bk ? key : bk; }
         }
       } else {
-        for (int j = l + 1; j <= ns; j += 16) {
+        for (int j = l + 1; j <= ns; j += LPP) {
           unsigned long long key = cand_key(VT::get(VT::from_bits(my_log[j]), h), iabs(refLen - j), j);
           bk = key > bk ? key : bk;
         }
       }
-      bk = row_max_u64(bk);
+      bk = group_max_u64<LPP>(bk);
       best = (int)(unsigned)(bk >> 24) - 0x40000000;
       const int order = 4095 - (int)(bk & 0xFFF);
       if (order == 0) { p1 = col_i; p2 = altLen; } else { p1 = refLen; p2 = order; }
@@ -279,22 +286,22 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
 // Restates calculateCigarOneBatch (FalconSW_AVX.cpp:2341-2417) on top of the bit planes: the walk, the
 // strategy-specific tail, alignment_offset and the final reversal.
 template <bool LANE_IS_ALT>
-__global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int p16, int sweep_cap) {
+__global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t wi = tid >> 3, slot = tid & 7;
   if (wi >= n_work) return;
   const uint32_t pair = a.work[work_base + wi].pair[slot];
   const int g = slot >> 1, half = slot & 1;
-  if (pair == SW_NO_PAIR || (!p16 && half)) return;
+  if (pair == SW_NO_PAIR || (!p16 && half) || g >= 64 / LPP) return;
   const int refLen = a.ref_len[pair], altLen = a.alt_len[pair], strat = a.strategy[pair];
   const int nl = LANE_IS_ALT ? altLen : refLen;
-  const int pad = 16 * K - nl;
-  const uint4* bt = a.bt + (uint64_t)(work_base + wi - bt_first) * a.bt_item_stride + (uint64_t)g * (sweep_cap + 16) * 16;
+  const int pad = LPP * K - nl;
+  const uint4* bt = a.bt + (uint64_t)(work_base + wi - bt_first) * a.bt_item_stride + (uint64_t)g * (sweep_cap + LPP) * LPP;
   // plane p of cell (i, j) (1-based reference coordinates)
   auto bit = [&](int i, int j, int plane) -> unsigned {
     const int sidx = LANE_IS_ALT ? i : j, pos = LANE_IS_ALT ? j : i;
     const int flat = pos - 1 + pad, l = flat / K, k = flat - l * K;
-    const unsigned* w = reinterpret_cast<const unsigned*>(bt + (uint64_t)(sidx + l) * 16 + l);
+    const unsigned* w = reinterpret_cast<const unsigned*>(bt + (uint64_t)(sidx + l) * LPP + l);
     return (w[plane] >> (K - 1 - k + 16 * half)) & 1u;
   };
   // planes: 0 lane-direction gap opened, 1 sweep-direction gap opened; "right" (insertion) runs along the alternate
@@ -345,46 +352,70 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   a.cig_n[pair] = n;
 }
 
-template <bool P16, bool LIA, bool BT>
+template <int LPP, bool P16, bool LIA, bool BT>
 hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first, int cap, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const size_t lds = sw_lds_bytes(cap);
-#define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, P16, LIA, BT>), dim3(n), dim3(64), lds, st, a, wb, bt_first, cap); break;
-  switch (K) {
-    ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
-    ACCG_CASE(9) ACCG_CASE(10) ACCG_CASE(11) ACCG_CASE(12) ACCG_CASE(13) ACCG_CASE(14) ACCG_CASE(15) ACCG_CASE(16)
-    default: return hipErrorInvalidValue;
+#define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, LPP, P16, LIA, BT>), dim3(n), dim3(64), lds, st, a, wb, bt_first, cap); break;
+  if (LPP == 16) {
+    switch (K) {
+      ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
+      ACCG_CASE(9) ACCG_CASE(10) ACCG_CASE(11) ACCG_CASE(12) ACCG_CASE(13) ACCG_CASE(14) ACCG_CASE(15) ACCG_CASE(16)
+      default: return hipErrorInvalidValue;
+    }
+  } else if (LPP == 32) {
+    switch (K) { ACCG_CASE(10) ACCG_CASE(12) ACCG_CASE(14) ACCG_CASE(16) default: return hipErrorInvalidValue; }
+  } else {
+    switch (K) { ACCG_CASE(10) ACCG_CASE(12) ACCG_CASE(14) ACCG_CASE(16) ACCG_CASE(20) ACCG_CASE(24) default: return hipErrorInvalidValue; }
   }
 #undef ACCG_CASE
   return hipGetLastError();
+}
+
+template <int LPP>
+hipError_t launch_sel(int K, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first,
+                      int cap, hipStream_t s) {
+  const int sel = (pack16 ? 4 : 0) | (lane_is_alt ? 2 : 0) | (with_bt ? 1 : 0);
+  switch (sel) {
+    case 0: return launch<LPP, false, false, false>(K, a, wb, n, bt_first, cap, s);
+    case 1: return launch<LPP, false, false, true>(K, a, wb, n, bt_first, cap, s);
+    case 2: return launch<LPP, false, true, false>(K, a, wb, n, bt_first, cap, s);
+    case 3: return launch<LPP, false, true, true>(K, a, wb, n, bt_first, cap, s);
+    case 4: return launch<LPP, true, false, false>(K, a, wb, n, bt_first, cap, s);
+    case 5: return launch<LPP, true, false, true>(K, a, wb, n, bt_first, cap, s);
+    case 6: return launch<LPP, true, true, false>(K, a, wb, n, bt_first, cap, s);
+    default: return launch<LPP, true, true, true>(K, a, wb, n, bt_first, cap, s);
+  }
 }
 
 }  // namespace
 
 size_t sw_lds_bytes(int sweep_cap) { return (size_t)8 * (sweep_cap + 1) * 4; }
 
-hipError_t sw_launch(int K, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t wb, uint32_t n,
+hipError_t sw_launch(int K, int lpp, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t wb, uint32_t n,
                      uint32_t bt_first, int cap, hipStream_t s) {
-  const int sel = (pack16 ? 4 : 0) | (lane_is_alt ? 2 : 0) | (with_bt ? 1 : 0);
-  switch (sel) {
-    case 0: return launch<false, false, false>(K, a, wb, n, bt_first, cap, s);
-    case 1: return launch<false, false, true>(K, a, wb, n, bt_first, cap, s);
-    case 2: return launch<false, true, false>(K, a, wb, n, bt_first, cap, s);
-    case 3: return launch<false, true, true>(K, a, wb, n, bt_first, cap, s);
-    case 4: return launch<true, false, false>(K, a, wb, n, bt_first, cap, s);
-    case 5: return launch<true, false, true>(K, a, wb, n, bt_first, cap, s);
-    case 6: return launch<true, true, false>(K, a, wb, n, bt_first, cap, s);
-    default: return launch<true, true, true>(K, a, wb, n, bt_first, cap, s);
-  }
+  if (lpp == 16) return launch_sel<16>(K, pack16, lane_is_alt, with_bt, a, wb, n, bt_first, cap, s);
+  if (lpp == 32) return launch_sel<32>(K, pack16, lane_is_alt, with_bt, a, wb, n, bt_first, cap, s);
+  return launch_sel<64>(K, pack16, lane_is_alt, with_bt, a, wb, n, bt_first, cap, s);
 }
 
-hipError_t sw_trace_launch(int K, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first,
+hipError_t sw_trace_launch(int K, int lpp, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first,
                            int cap, hipStream_t s) {
   if (n == 0) return hipSuccess;
   const uint32_t threads = n * 8, block = 64, grid = (threads + block - 1) / block;
-  if (lane_is_alt) hipLaunchKernelGGL((sw_trace_kernel<true>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, (int)pack16, cap);
-  else hipLaunchKernelGGL((sw_trace_kernel<false>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, (int)pack16, cap);
+  if (lane_is_alt) hipLaunchKernelGGL((sw_trace_kernel<true>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap);
+  else hipLaunchKernelGGL((sw_trace_kernel<false>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap);
   return hipGetLastError();
+}
+
+// K actually instantiated for a lane sequence of nl positions spread over lpp lanes (0 = not supported)
+int sw_pick_k(int nl, int lpp) {
+  const int need = (nl + 1 + lpp - 1) / lpp;
+  if (lpp == 16) return need <= 16 ? need : 0;
+  static const int k32[] = {10, 12, 14, 16}, k64[] = {10, 12, 14, 16, 20, 24};
+  if (lpp == 32) { for (int k : k32) if (k >= need) return k; return 0; }
+  for (int k : k64) if (k >= need) return k;
+  return 0;
 }
 
 }  // namespace accg

@@ -98,8 +98,8 @@ void accg_phmm_batch_destroy(accg_phmm_batch* b);
  * Results per pair: score = sw[p1][p2] and the end cell (p1, p2) that calculateCigarOneBatch starts its
  * backtrace from -- bit-exact with the CPU path.  (The CIGAR itself is SURVEY.md 8f row 3: next.)
  * strategies: per pair, 0 SOFTCLIP, 1 INDEL, 2 LEADING_INDEL, 3 IGNORE (common.h:15-18); NULL = all SOFTCLIP.
- * Limits of this round: 1 <= length <= ACCG_SW_MAX_LEN and min(ref_len, alt_len) <= ACCG_SW_MAX_SHORT. */
-#define ACCG_SW_MAX_SHORT 255
+ * Limits: 1 <= length <= ACCG_SW_MAX_LEN (the reference's MAX_SEQ_LENGTH - 1) for both sequences.  The shorter one is
+ * spread over 16 lanes (<= 255), 32 lanes (<= 511) or a whole wavefront (<= 1535). */
 int accg_sw_batch_create(accg_ctx* ctx, int n_pairs, const uint8_t* refs, size_t ref_stride, const int32_t* ref_lens,
                          const uint8_t* alts, size_t alt_stride, const int32_t* alt_lens, const uint8_t* strategies,
                          int w_match, int w_mismatch, int w_open, int w_extend, accg_sw_batch** out);

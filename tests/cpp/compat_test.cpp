@@ -83,10 +83,10 @@ static int test_sw() {
   if (!FalconSWFPGA_init((char*)"unused")) { printf("sw init failed\n"); return 1; }
   for (int B = 1; B <= 128; B *= 2)                    // batch 1,2,4..128 as sw_host.cpp:240
     for (int strategy = 0; strategy < 4; strategy++) {
-      char ref[MAX_SEQ_LENGTH]; int rl = 60 + (int)(rng() % 190);            // keeps min(len) <= 255 (this round's limit)
+      char ref[MAX_SEQ_LENGTH]; int rl = 60 + (int)(rng() % 450);            // ref length 60..509 as sw_host.cpp:150
       for (int k = 0; k < rl; k++) ref[k] = base();
       for (int b = 0; b < B; b++) {                    // alt = ref prefix +-10 with 10 % substitutions (sw_host.cpp:160-180)
-        int al = rl - 11 + (int)(rng() % 22); if (al < 1) al = 1; if (al > 255) al = 255;
+        int al = rl - 11 + (int)(rng() % 22); if (al < 1) al = 1; if (al > 510) al = 510;
         altLen[b] = al;
         for (int k = 0; k < al; k++) alts[b][k] = (k < rl && rng() % 10) ? ref[k] : base();
       }

@@ -58,12 +58,14 @@ def _ragged(rng, n, rmin, rmax, amin, amax):
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 1, 40), (10, 80, 100, 400), (100, 400, 10, 80), (200, 255, 200, 255),
-                                   (250, 255, 900, 1535), (1400, 1535, 1, 30), (17, 17, 300, 300)])
+                                   (250, 255, 900, 1535), (1400, 1535, 1, 30), (17, 17, 300, 300),
+                                   (256, 330, 256, 330), (300, 511, 400, 700), (480, 520, 500, 530), (512, 700, 600, 900),
+                                   (1000, 1100, 1020, 1535), (1500, 1535, 1500, 1535)])
 def test_ragged_all_strategies(ctx, shape):
     """Every orientation (lanes = alt or = ref), both arithmetic modes (16-bit packed / int32), every
     K, odd group fill, mixed strategies inside one batch."""
     rng = synth.rng_for(400 + shape[0] + shape[2])
-    n = 203
+    n = 203 if shape[1] < 600 else 37
     refs, rl, alts, al = _ragged(rng, n, *shape)
     strat = rng.integers(0, 4, size=n).astype(np.uint8)
     with A.SwBatch(ctx, refs, rl, alts, al, strategies=strat) as b:
@@ -149,7 +151,7 @@ def test_full_size_c2_properties(ctx):
 
 def test_error_paths(ctx):
     one = np.frombuffer(b"ACGT", np.uint8)[None, :]
-    for rl, al, status in ((0, 4, -6), (4, 0, -6), (4, 1536, -7), (300, 300, -7)):
+    for rl, al, status in ((0, 4, -6), (4, 0, -6), (4, 1536, -7), (1536, 1536, -7)):
         refs = np.zeros((1, max(rl, 4)), np.uint8); alts = np.zeros((1, max(al, 4)), np.uint8)
         with pytest.raises(A.AccgError) as e:
             A.SwBatch(ctx, refs, np.array([rl], np.int32), alts, np.array([al], np.int32))
@@ -186,14 +188,15 @@ def test_golden_cigars(ctx, path):
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 1, 40), (10, 80, 100, 400), (100, 400, 10, 80), (200, 255, 200, 255),
-                                   (250, 255, 900, 1535), (17, 17, 300, 300)])
+                                   (250, 255, 900, 1535), (17, 17, 300, 300), (256, 330, 256, 330), (300, 511, 400, 700),
+                                   (512, 700, 600, 900), (1500, 1535, 1500, 1535)])
 def test_ragged_cigars(ctx, shape):
     rng = synth.rng_for(500 + shape[0] + shape[2])
-    n = 61
+    n = 61 if shape[1] < 600 else 13
     refs, rl, alts, al = _ragged(rng, n, *shape)
     strat = rng.integers(0, 4, size=n).astype(np.uint8)
     with A.SwBatch(ctx, refs, rl, alts, al, strategies=strat) as b:
-        b.run_cigar(96)
+        b.run_cigar(256)
         n_el, off, el = b.cigars()
     for k in range(n):
         wn, woff, wcig = _oracle_cigar(refs[k, :rl[k]].tobytes(), alts[k, :al[k]].tobytes(), int(strat[k]))
