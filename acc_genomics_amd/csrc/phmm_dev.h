@@ -5,21 +5,20 @@
 
 namespace accg {
 
-constexpr int PHMM_LANES = 16;          // lanes per read (one DPP row)
-constexpr int PHMM_GROUPS = 4;          // reads per wavefront
+constexpr int PHMM_GROUPS = 4;          // reads per wavefront (read <= 255 bp; 2 for <= 511, 1 for <= 1023)
 constexpr int PHMM_MAX_K = 16;          // rows per lane
 constexpr int PHMM_STREAM_MAX = 4096;   // haplotype stream entries per work item (bubbles included)
 constexpr int PHMM_HAPS_MAX = 48;       // haplotypes per work item
 
 // Dynamic LDS of one wavefront, in bytes, as laid out by phmm_kernel:
 //   [dist table: nchar x QT x 64 lanes x 16 B][y0: T x (haps_cap+1)][hcol: u32 x (haps_cap+1)]
-//   [bpos: u32 x (haps_cap+2)][stream: u8 x (15 + stream_cap + 40)]
+//   [bpos: u32 x (haps_cap+2)][stream: u8 x (lpp-1 + stream_cap + lpp+20)]
 // nchar = 4 (A C G T) or 5 (+N) -- the N slab is only carried when some haplotype of the batch has an N.
 constexpr int phmm_qt(int K, int elem_bytes) { return (K * elem_bytes + 15) / 16; }
 constexpr size_t phmm_align16(size_t x) { return (x + 15) / 16 * 16; }
-constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap) {
+constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16) {
   return (size_t)nchar * phmm_qt(K, elem_bytes) * 1024 + phmm_align16((size_t)(haps_cap + 1) * elem_bytes) +
-         phmm_align16((size_t)(2 * haps_cap + 3) * 4) + phmm_align16((size_t)15 + stream_cap + 40);
+         phmm_align16((size_t)(2 * haps_cap + 3) * 4) + phmm_align16((size_t)2 * lpp + stream_cap + 24);
 }
 constexpr uint32_t PHMM_NO_READ = 0xFFFFFFFFu;
 
@@ -64,12 +63,13 @@ struct PhmmArgs {
 
 // Launchers (phmm_kernel.hip). K = rows per lane, 1..PHMM_MAX_K.
 // a.stream_cap / a.haps_cap = largest haplotype stream (entries, bubbles included) / haplotype count among the jobs of this launch.
-hipError_t phmm_launch_f32(int K, bool strict, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+void phmm_pick(uint32_t read_len, int* lpp, int* K);
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 // fp64 rescue pass: same jobs as the fp32 pass; a wavefront redoes only the haplotypes for which one of
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.
-hipError_t phmm_launch_rescue_f64(int K, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+hipError_t phmm_launch_rescue_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
-hipError_t phmm_launch_f64(int K, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 constexpr float PHMM_MIN_ACCEPTED = 1e-28f;   // host_type.h:21
 
 }  // namespace accg

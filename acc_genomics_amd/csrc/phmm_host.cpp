@@ -103,7 +103,7 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K; uint32_t work0, n_work; int stream_cap, haps_cap; };
+struct KLaunch { int K, lpp; uint32_t work0, n_work; int stream_cap, haps_cap; };
 
 template <typename T>
 struct DevBuf {
@@ -189,7 +189,6 @@ int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<Se
   return n;
 }
 
-inline int k_for(uint32_t read_len) { return (int)((read_len + 1 + 15) / 16); }   // one row reserved as "row 0"
 
 // Resident wavefronts per CU for the fp32 kernel at K rows per lane: LDS (160 KiB) and VGPR (512 per SIMD lane) limits.
 int waves_per_cu(int K, int nchar, int stream_cap, int haps_cap) {
@@ -229,7 +228,7 @@ void partition(accg_phmm_batch& b) {
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
   // quads per region, by descending read length so that the four reads of a wavefront need the same K
-  struct Quad { uint32_t read[4]; int K; };
+  struct Quad { uint32_t read[4]; int K, lpp; };
   std::vector<std::vector<Quad>> quads(b.regions.size());
   uint64_t kw[PHMM_MAX_K + 1] = {0};
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
@@ -238,14 +237,12 @@ void partition(accg_phmm_batch& b) {
     std::vector<uint32_t> order(r.n_reads);
     std::iota(order.begin(), order.end(), r.read0);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b.rd[x].len > b.rd[y].len; });
-    for (uint32_t q = 0; q < (r.n_reads + 3) / 4; q++) {
-      Quad Q; uint32_t maxlen = 0;
-      for (int g = 0; g < PHMM_GROUPS; g++) {
-        const uint32_t i = q * 4 + g;
-        Q.read[g] = i < r.n_reads ? order[i] : PHMM_NO_READ;
-        if (i < r.n_reads) maxlen = std::max(maxlen, b.rd[order[i]].len);
-      }
-      Q.K = k_for(maxlen);
+    for (uint32_t i = 0; i < r.n_reads;) {        // the longest read of a wavefront decides lanes per read and K
+      Quad Q;
+      phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K);
+      const uint32_t per = 64 / Q.lpp;
+      for (uint32_t g = 0; g < PHMM_GROUPS; g++) Q.read[g] = (g < per && i + g < r.n_reads) ? order[i + g] : PHMM_NO_READ;
+      i += per;
       quads[ri].push_back(Q);
       kw[Q.K] += (uint64_t)r.n_haps;
     }
@@ -296,7 +293,7 @@ void partition(accg_phmm_batch& b) {
     if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
   }
 
-  struct Job { PhmmWork w; int K; uint64_t cost; uint32_t stream_len; };
+  struct Job { PhmmWork w; int K, lpp; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (quads[ri].empty()) continue;
@@ -314,16 +311,19 @@ void partition(accg_phmm_batch& b) {
       w.pad_[0] = w.pad_[1] = 0;
       for (size_t c = 0; c < runs.size(); c++) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
-        jobs.push_back({w, Q.K, (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
+        jobs.push_back({w, Q.K, Q.lpp, (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
       }
     }
   }
   // one launch per K; inside a launch the longest jobs go first so the tail is short
-  std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.K != y.K ? x.K > y.K : x.cost > y.cost; });
+  std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
+    return x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.cost > y.cost;
+  });
   b.work.resize(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     b.work[i] = jobs[i].w;
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K) b.launches.push_back({jobs[i].K, (uint32_t)i, 0, 0, 0});
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp)
+      b.launches.push_back({jobs[i].K, jobs[i].lpp, (uint32_t)i, 0, 0, 0});
     KLaunch& L = b.launches.back();
     L.n_work++;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
@@ -345,7 +345,7 @@ int launch_f32(accg_phmm_batch* b, int mode) {
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    ACCG_HIP(phmm_launch_f32(l.K, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, b->ctx->stream));
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, b->ctx->stream));
   }
   return ACCG_OK;
 }
@@ -354,7 +354,7 @@ int launch_rescue(accg_phmm_batch* b) {
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    ACCG_HIP(phmm_launch_rescue_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+    ACCG_HIP(phmm_launch_rescue_f64(l.K, l.lpp, a, l.work0, l.n_work, b->ctx->stream));
   }
   return ACCG_OK;
 }
@@ -446,7 +446,7 @@ extern "C" int accg_phmm_batch_run_f64(accg_phmm_batch* b) {
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    ACCG_HIP(phmm_launch_f64(l.K, a, l.work0, l.n_work, b->ctx->stream));
+    ACCG_HIP(phmm_launch_f64(l.K, l.lpp, a, l.work0, l.n_work, b->ctx->stream));
   }
   return ACCG_OK;
 }

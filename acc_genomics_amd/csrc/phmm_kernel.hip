@@ -9,7 +9,8 @@
 //     result  = sum_c (M[R][c] + X[R][c]),   Y[0][c] = INIT/H, everything else on the border 0.
 //
 // How it is mapped (a design of its own, neither the FPGA PE array nor the AVX stripes):
-//   * one wavefront = four reads; read g lives in DPP row g (16 lanes); lane l of the row owns K
+//   * one wavefront = four reads (reads > 255 bp: two reads on 32 lanes each, > 511 bp: one read on all 64);
+//     read g lives in DPP row g (16 lanes); lane l of the row owns K
 //     consecutive read rows in registers (K = ceil((R+1)/16) is a template parameter, so all row
 //     state is register-resident and indexed at compile time).  Rows are right-aligned: the last
 //     read row is always (lane 15, k = K-1); the rows in front are clones of "row 0"
@@ -39,14 +40,19 @@ __device__ __forceinline__ int char_index(uint8_t b) {   // bases are validated 
   return b == 'A' ? CH_A : b == 'C' ? CH_C : b == 'G' ? CH_G : b == 'T' ? CH_T : CH_N;
 }
 
-// lane l <- lane l-1 inside each row of 16; lane 0 of a row receives 0.
-__device__ __forceinline__ float row_shr1(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+// lane l <- lane l-1 inside a group of LPP lanes; the first lane of a group receives 0.
+// LPP = 16: DPP row_shr:1.  LPP = 32 / 64: wave_shr:1 (lane 32's source is lane 31, the last lane of the
+// other group, whose a_out / x_out are 0 by construction when LPP = 32 - see the lane-constant setup).
+template <int LPP>
+__device__ __forceinline__ int shr1_bits(int v) {
+  return LPP == 16 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
 }
-__device__ __forceinline__ double row_shr1(double v) {
+template <int LPP>
+__device__ __forceinline__ float group_shr1(float v) { return __builtin_bit_cast(float, shr1_bits<LPP>(__builtin_bit_cast(int, v))); }
+template <int LPP>
+__device__ __forceinline__ double group_shr1(double v) {
   long long b = __builtin_bit_cast(long long, v);
-  int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x111, 0xF, 0xF, true);
-  int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, true);
+  int lo = shr1_bits<LPP>((int)b), hi = shr1_bits<LPP>((int)(b >> 32));
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
@@ -96,10 +102,10 @@ __device__ __forceinline__ void load_dist(const unsigned char* tab_lane, unsigne
 }
 
 // One column for every lane.  d[k] = dist of local row k against this lane's column.
-template <bool STRICT, typename T, int K>
+template <bool STRICT, int LPP, typename T, int K>
 __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
-  T a_in = row_shr1(s.a_out);
-  T x_in = row_shr1(s.x_out);
+  T a_in = group_shr1<LPP>(s.a_out);
+  T x_in = group_shr1<LPP>(s.x_out);
   // pass 1: everything that reads the previous column's state
   s.a_out = diag_term<STRICT>(s.M[K - 1], s.X[K - 1], s.Y[K - 1], s.nMM, s.nGM);
   T Mn[K], Yn[K];
@@ -119,12 +125,14 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
 #pragma unroll
   for (int k = 0; k < K; k++) { s.M[k] = Mn[k]; s.Y[k] = Yn[k]; }
   s.x_out = mul_add2<STRICT>(s.M[K - 1], s.nMX, s.X[K - 1], s.nXX);
-  s.acc = s.acc + s.x_out;   // lane 15: x_out == M + X of the last read row (baseline_impl.cpp:91)
+  // last lane of a group: M + X of the last read row (baseline_impl.cpp:91).  With one or four groups per wave it is
+  // x_out itself (nMX = nXX = 1, nobody consumes it); with two groups lane 31's x_out must stay 0 for lane 32.
+  s.acc = s.acc + (LPP == 32 ? s.M[K - 1] + s.X[K - 1] : s.x_out);
 }
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
-template <typename T, int K, bool STRICT, bool RESCUE>
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE>
 __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
@@ -137,13 +145,14 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   uint8_t* stream = reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4);
 
   const int lane = threadIdx.x;
-  const int g = lane >> 4, l = lane & 15;
+  constexpr int NG = 64 / LPP;              // reads per wavefront
+  const int g = lane / LPP, l = lane % LPP;
   // (field-wise loads: indexing a by-value copy of the struct with g would put it in scratch)
   const PhmmWork* wp = a.work + (work_base + job);
   const int n_list = __builtin_amdgcn_readfirstlane((int)wp->n_haps);
   const uint32_t hap_off = __builtin_amdgcn_readfirstlane(wp->hap_off);
 
-  const uint32_t ridx = wp->read[g];
+  const uint32_t ridx = wp->read[g < NG ? g : 0];
   const bool have = ridx != PHMM_NO_READ;
   SeqRef rr = {0u, 0u};
   uint32_t out_base = 0;
@@ -154,24 +163,24 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   // (their dist value is never kept: M is forced to 0 on a bubble, and all state is 0 in the padding)
   int pos = 0, n_haps = 0;
   unsigned n_flag = 0;
-  for (int i = lane; i < 15; i += 64) stream[i] = 0;
+  for (int i = lane; i < LPP - 1; i += 64) stream[i] = 0;
   for (int j = 0; j < n_list; j++) {
     const uint32_t gh = a.hap_ids[hap_off + j];
     const uint32_t col = a.hp_local[gh];
     if (RESCUE) {   // keep this haplotype only if one of the four reads underflowed in fp32 against it
-      const bool under = have && l == 0 && a.raw[out_base + col] < PHMM_MIN_ACCEPTED;
+      const bool under = have && g < NG && l == 0 && a.raw[out_base + col] < PHMM_MIN_ACCEPTED;
       const unsigned long long m = __ballot(under);
       if (m == 0) continue;
       n_flag += (unsigned)__popcll(m);
     }
     const SeqRef hr = a.hp[gh];
     if (lane == 0) {
-      stream[15 + pos] = 0;
+      stream[LPP - 1 + pos] = 0;
       bpos[n_haps] = pos;
       y0s[n_haps] = a.tab.init / (T)(int)hr.len;     // baseline_impl.cpp:63
       hcol[n_haps] = col;
     }
-    for (int i = lane; i < (int)hr.len; i += 64) stream[15 + pos + 1 + i] = (uint8_t)char_index(a.hblob[hr.off + i]);
+    for (int i = lane; i < (int)hr.len; i += 64) stream[LPP - 1 + pos + 1 + i] = (uint8_t)char_index(a.hblob[hr.off + i]);
     pos += (int)hr.len + 1;
     n_haps++;
   }
@@ -180,13 +189,13 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     if (lane == 0) atomicAdd(a.n_rescued, (unsigned long long)n_flag);
   }
   if (lane == 0) { bpos[n_haps] = pos; bpos[n_haps + 1] = 0x7FFFFFFF; y0s[n_haps] = T(0); hcol[n_haps] = 0; }
-  for (int i = lane; i < 36; i += 64) stream[15 + pos + i] = 0;       // terminal bubble + drain + prefetch slack
-  const int t_end = __builtin_amdgcn_readfirstlane(pos + 16);          // lane 15 passes the terminal bubble at pos+15
+  for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = 0;   // terminal bubble + drain + prefetch slack
+  const int t_end = __builtin_amdgcn_readfirstlane(pos + LPP);         // the last lane passes the terminal bubble at pos+LPP-1
 
   // ---- per-row constants (registers) and the dist table (LDS) ---------------------------------
   Rows<T, K> s;
   const int R = (int)rr.len;
-  const int pad = 16 * K - R;               // >= 1 by construction of the job
+  const int pad = LPP * K - R;              // >= 1 by construction of the job
   const uint8_t* rb = a.rblob + rr.off;
   s.npad = pad - l * K;                     // clones are the first `pad` flat rows
   typedef typename Vec16<T>::type V;
@@ -231,14 +240,14 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   }
   {
     const int r = (l + 1) * K - pad;        // row 0 of the lane to the right
-    if (l < 15 && r >= 0) {
+    if (l < LPP - 1 && r >= 0) {
       const int qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
       const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
       s.nMM = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];
       s.nGM = a.tab.omph[qc];
       s.nMX = a.tab.ph[qi];
       s.nXX = a.tab.ph[qc];
-    } else if (l == 15) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
+    } else if (l == LPP - 1 && LPP != 32) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
     else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
   if (!STRICT) {
@@ -250,11 +259,11 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   __builtin_amdgcn_wave_barrier();
 
   // ---- sweep ----------------------------------------------------------------------------------
-  const uint8_t* hs = stream + 15 - l;                // hs[t] = this lane's column at step t (base index 0..4)
+  const uint8_t* hs = stream + LPP - 1 - l;           // hs[t] = this lane's column at step t (base index 0..4)
   const unsigned char* tab_lane = tab + lane * 16;
   int t = 0, jn = 0, jl = -1;
   int nb = 0;                 // stream position of the next bubble lane 0 will meet
-  unsigned rm = 0;            // bit i: lane i of every row is on a bubble this step
+  unsigned long long rm = 0;  // bit i: lane i of every group is on a bubble this step
   T dn[K];                    // dist of step t   (loaded one step ahead)
   load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
   unsigned o1 = hs[1];        // base index of step t+1 (loaded two steps ahead)
@@ -268,28 +277,28 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
         for (int k = 0; k < K; k++) d[k] = dn[k];
         load_dist<T, K>(tab_lane, o1 * SLAB, dn);
         o1 = hs[t + u + 2];
-        column<STRICT>(s, d);
+        column<STRICT, LPP>(s, d);
       }
       t += U;
       continue;
     }
     const bool nbit = (t == nb);
     if (nbit) { jn++; nb = __builtin_amdgcn_readfirstlane((int)bpos[jn]); }
-    rm = ((rm << 1) | (nbit ? 1u : 0u)) & 0xFFFFu;
+    rm = ((rm << 1) | (nbit ? 1ull : 0ull)) & (LPP == 64 ? ~0ull : ((1ull << (LPP & 63)) - 1));
     T d[K];
 #pragma unroll
     for (int k = 0; k < K; k++) d[k] = dn[k];
     load_dist<T, K>(tab_lane, o1 * SLAB, dn);
     o1 = hs[t + 2];
-    if (rm == 0) { column<STRICT>(s, d); t++; continue; }     // the last few columns in front of a bubble
+    if (rm == 0) { column<STRICT, LPP>(s, d); t++; continue; }     // the last few columns in front of a bubble
     // Some lane (one per row of 16) is on a bubble = column 0 of its next haplotype.  Everybody runs the
     // ordinary column; that lane then overwrites its state with the column-0 border
     // (M = X = 0, Y = 0, clones of row 0: Y = INIT/H; baseline_impl.cpp:60-70) under EXEC.
-    const bool rst = (rm >> l) & 1u;
+    const bool rst = (rm >> l) & 1ull;
     T acc_done = s.acc;
-    column<STRICT>(s, d);
+    column<STRICT, LPP>(s, d);
     if (rst) {
-      if (l == 15 && jl >= 0 && have) a.out[out_base + hcol[jl]] = acc_done;   // haplotype jl is complete
+      if (l == LPP - 1 && jl >= 0 && have) a.out[out_base + hcol[jl]] = acc_done;   // haplotype jl is complete
       jl++;
       const T y0 = y0s[jl];
 #pragma unroll
@@ -306,18 +315,24 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
 }
 
 template <typename T, bool STRICT, bool RESCUE>
-hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
+hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
   if (n_work == 0) return hipSuccess;
   dim3 grid(n_work), block(64);
-#define ACCG_CASE(KK)                                                                                         \
+#define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
-    const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap);                 \
-    hipLaunchKernelGGL((phmm_kernel<T, KK, STRICT, RESCUE>), grid, block, lds, st, a, work_base);             \
+    const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL);             \
+    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE>), grid, block, lds, st, a, work_base);         \
   } break;
-  switch (K) {
-    ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
-    ACCG_CASE(9) ACCG_CASE(10) ACCG_CASE(11) ACCG_CASE(12) ACCG_CASE(13) ACCG_CASE(14) ACCG_CASE(15) ACCG_CASE(16)
-    default: return hipErrorInvalidValue;
+  if (lpp == 16) {
+    switch (K) {
+      ACCG_CASE(1, 16) ACCG_CASE(2, 16) ACCG_CASE(3, 16) ACCG_CASE(4, 16) ACCG_CASE(5, 16) ACCG_CASE(6, 16) ACCG_CASE(7, 16) ACCG_CASE(8, 16)
+      ACCG_CASE(9, 16) ACCG_CASE(10, 16) ACCG_CASE(11, 16) ACCG_CASE(12, 16) ACCG_CASE(13, 16) ACCG_CASE(14, 16) ACCG_CASE(15, 16) ACCG_CASE(16, 16)
+      default: return hipErrorInvalidValue;
+    }
+  } else if (lpp == 32) {
+    switch (K) { ACCG_CASE(9, 32) ACCG_CASE(10, 32) ACCG_CASE(12, 32) ACCG_CASE(14, 32) ACCG_CASE(16, 32) default: return hipErrorInvalidValue; }
+  } else {
+    switch (K) { ACCG_CASE(9, 64) ACCG_CASE(10, 64) ACCG_CASE(12, 64) ACCG_CASE(14, 64) ACCG_CASE(16, 64) default: return hipErrorInvalidValue; }
   }
 #undef ACCG_CASE
   return hipGetLastError();
@@ -325,14 +340,26 @@ hipError_t launch(int K, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_wo
 
 }  // namespace
 
-hipError_t phmm_launch_f32(int K, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return strict ? launch<float, true, false>(K, a, wb, n, s) : launch<float, false, false>(K, a, wb, n, s);
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return strict ? launch<float, true, false>(K, lpp, a, wb, n, s) : launch<float, false, false>(K, lpp, a, wb, n, s);
 }
-hipError_t phmm_launch_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, false>(K, a, wb, n, s);
+hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return launch<double, true, false>(K, lpp, a, wb, n, s);
 }
-hipError_t phmm_launch_rescue_f64(int K, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, true>(K, a, wb, n, s);
+hipError_t phmm_launch_rescue_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return launch<double, true, true>(K, lpp, a, wb, n, s);
+}
+
+// (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support
+void phmm_pick(uint32_t len, int* lpp, int* K) {
+  const uint32_t rows = len + 1;            // one row reserved as "row 0"
+  if (rows <= 256) { *lpp = 16; *K = (int)((rows + 15) / 16); return; }
+  static const int ks[] = {9, 10, 12, 14, 16};
+  for (int l : {32, 64}) {
+    const int need = (int)((rows + l - 1) / l);
+    for (int k : ks) if (k >= need) { *lpp = l; *K = k; return; }
+  }
+  *lpp = 64; *K = 0;
 }
 
 }  // namespace accg

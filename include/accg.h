@@ -28,7 +28,7 @@ enum {
   ACCG_ERR_NOMEM = -9
 };
 
-#define ACCG_PHMM_MAX_READ 255   /* rows held in registers: 16 lanes x 16 rows, one row reserved */
+#define ACCG_PHMM_MAX_READ 1023  /* rows held in registers: up to 64 lanes x 16 rows, one row reserved */
 #define ACCG_PHMM_MAX_HAP 4000   /* one haplotype must fit the per-wave LDS stream */
 #define ACCG_SW_MAX_LEN 1535     /* htc-sw/host/common.h:13 MAX_SEQ_LENGTH - 1 */
 
