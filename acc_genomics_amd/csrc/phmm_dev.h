@@ -56,10 +56,41 @@ struct PhmmArgs {
   T* out;
   const float* raw;           // rescue pass only: the fp32 results that decide which pairs are redone
   unsigned long long* n_rescued;  // rescue pass only: count of (read, hap) pairs below the threshold
+  const uint32_t* job_count;      // rescue pass only: number of valid jobs (device-side); blocks beyond it exit
+  uint32_t* read_flag;            // fp32 pass: set to 1 for a read with a result below MIN_ACCEPTED (nullable)
   PhmmTables<T> tab;
   int nchar;                  // 4 or 5 slabs in the dist table
   int stream_cap, haps_cap;   // LDS capacities of this launch (entries / haplotypes per job)
 };
+
+// ---- fp64 rescue planning (device side, no host round trip) -----------------------------------------
+// Reads that underflowed in fp32 against at least one haplotype are regrouped into new wavefront jobs so that
+// the fp64 pass only carries those reads (FalconPairHMM.cpp:636-652 redoes exactly the underflowed pairs).
+constexpr int PHMM_RESCUE_CLASSES = 6;    // (lanes per read, K): (16,4) (16,8) (16,12) (16,16) (32,16) (64,16)
+__host__ __device__ inline void phmm_rescue_class(uint32_t len, int* cls, int* lpp, int* K) {
+  const uint32_t rows = len + 1;
+  if (rows <= 64) { *cls = 0; *lpp = 16; *K = 4; }
+  else if (rows <= 128) { *cls = 1; *lpp = 16; *K = 8; }
+  else if (rows <= 192) { *cls = 2; *lpp = 16; *K = 12; }
+  else if (rows <= 256) { *cls = 3; *lpp = 16; *K = 16; }
+  else if (rows <= 512) { *cls = 4; *lpp = 32; *K = 16; }
+  else { *cls = 5; *lpp = 64; *K = 16; }
+}
+struct PhmmRegionDev { uint32_t read0, n_reads, chunk0, n_chunks, n_haps, pad_; };
+struct PhmmChunkDev { uint32_t ids0, n; };
+struct PhmmPlanArgs {
+  const PhmmRegionDev* regions;
+  const PhmmChunkDev* chunks;
+  const uint32_t* sorted_reads;   // per region: its reads by descending length (global ids), at [read0, read0 + n_reads)
+  const SeqRef* rd;
+  const uint32_t* rd_out;
+  const uint32_t* read_flag;      // written by the fp32 pass
+  PhmmWork* jobs;                 // PHMM_RESCUE_CLASSES arrays of `cap` jobs each
+  uint32_t* counts;               // jobs written per class
+  uint32_t* flagged;              // scratch, one slot per read
+  uint32_t cap;
+};
+hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s);
 
 // Launchers (phmm_kernel.hip). K = rows per lane, 1..PHMM_MAX_K.
 // a.stream_cap / a.haps_cap = largest haplotype stream (entries, bubbles included) / haplotype count among the jobs of this launch.

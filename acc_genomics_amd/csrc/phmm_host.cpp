@@ -143,7 +143,17 @@ struct accg_phmm_batch {
   DevBuf<PhmmWork> d_work;
   DevBuf<float> d_out;
   DevBuf<double> d_out64;
-  DevBuf<unsigned long long> d_nresc;
+  // device-side rescue planning
+  std::vector<PhmmRegionDev> regions_dev;
+  std::vector<PhmmChunkDev> chunks_dev;
+  std::vector<uint32_t> sorted_reads;
+  uint32_t rescue_bound[PHMM_RESCUE_CLASSES] = {0};   // host-side upper bound of rescue jobs per class
+  uint32_t rescue_cap = 0; int rescue_stream_cap = 0, rescue_haps_cap = 0;
+  DevBuf<PhmmRegionDev> d_regions;
+  DevBuf<PhmmChunkDev> d_chunks;
+  DevBuf<uint32_t> d_sorted_reads, d_flagged;
+  DevBuf<uint32_t> d_state;   // zeroed per run: [n_reads] read flags, [6] rescue job counts, [2] n_rescued (u64)
+  DevBuf<PhmmWork> d_rescue_jobs;
   uint64_t last_kernel_ns = 0;
 };
 
@@ -230,6 +240,8 @@ void partition(accg_phmm_batch& b) {
   // quads per region, by descending read length so that the four reads of a wavefront need the same K
   struct Quad { uint32_t read[4]; int K, lpp; };
   std::vector<std::vector<Quad>> quads(b.regions.size());
+  b.sorted_reads.assign(b.rd.size(), 0);
+  b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
   uint64_t kw[PHMM_MAX_K + 1] = {0};
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     const Region& r = b.regions[ri];
@@ -237,6 +249,7 @@ void partition(accg_phmm_batch& b) {
     std::vector<uint32_t> order(r.n_reads);
     std::iota(order.begin(), order.end(), r.read0);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b.rd[x].len > b.rd[y].len; });
+    std::copy(order.begin(), order.end(), b.sorted_reads.begin() + r.read0);
     for (uint32_t i = 0; i < r.n_reads;) {        // the longest read of a wavefront decides lanes per read and K
       Quad Q;
       phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K);
@@ -301,9 +314,19 @@ void partition(accg_phmm_batch& b) {
     std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
     chunk_region(b, r, best_budget, runs, lens);
     std::vector<uint32_t> ids0;
-    for (auto& run : runs) {
+    b.regions_dev[ri] = {r.read0, r.n_reads, (uint32_t)b.chunks_dev.size(), (uint32_t)runs.size(), r.n_haps, 0};
+    for (size_t c = 0; c < runs.size(); c++) {
+      auto& run = runs[c];
       ids0.push_back((uint32_t)b.hap_ids.size());
+      b.chunks_dev.push_back({(uint32_t)b.hap_ids.size(), run.second});
       for (uint32_t k = 0; k < run.second; k++) b.hap_ids.push_back(r.hap0 + run.first + k);
+      b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((lens[c] + 63) / 64 * 64));
+      b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)run.second);
+    }
+    {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
+      uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
+      for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
+      for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += per_class[c] * (uint32_t)runs.size();
     }
     for (const Quad& Q : quads[ri]) {
       PhmmWork w;
@@ -331,17 +354,24 @@ void partition(accg_phmm_batch& b) {
   }
 }
 
+// layout of accg_phmm_batch::d_state (uint32 words)
+size_t state_counts(const accg_phmm_batch& b) { return (b.rd.size() + 1) / 2 * 2; }
+size_t state_nresc(const accg_phmm_batch& b) { return state_counts(b) + 8; }
+size_t state_words(const accg_phmm_batch& b) { return state_nresc(b) + 2; }
+
 template <typename T>
 PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab) {
   PhmmArgs<T> a;
   a.rblob = b.d_rblob.p; a.hblob = b.d_hblob.p; a.rd = b.d_rd.p; a.rd_out = b.d_rd_out.p; a.hp = b.d_hp.p;
   a.hp_local = b.d_hp_local.p; a.hap_ids = b.d_hap_ids.p; a.work = b.d_work.p; a.out = out;
-  a.raw = b.d_out.p; a.n_rescued = b.d_nresc.p; a.tab = tab;
-  a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0;
+  a.raw = b.d_out.p; a.n_rescued = reinterpret_cast<unsigned long long*>(b.d_state.p + state_nresc(b)); a.tab = tab;
+  a.read_flag = b.d_state.p;
+  a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0; a.job_count = nullptr;
   return a;
 }
 
 int launch_f32(accg_phmm_batch* b, int mode) {
+  ACCG_HIP(hipMemsetAsync(b->d_state.p, 0, state_words(*b) * sizeof(uint32_t), b->ctx->stream));   // flags, counts, n_rescued
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
@@ -350,11 +380,21 @@ int launch_f32(accg_phmm_batch* b, int mode) {
   return ACCG_OK;
 }
 int launch_rescue(accg_phmm_batch* b) {
-  ACCG_HIP(hipMemsetAsync(b->d_nresc.p, 0, sizeof(unsigned long long), b->ctx->stream));
+  hipStream_t s = b->ctx->stream;
+  PhmmPlanArgs p;
+  p.regions = b->d_regions.p; p.chunks = b->d_chunks.p; p.sorted_reads = b->d_sorted_reads.p; p.rd = b->d_rd.p;
+  p.rd_out = b->d_rd_out.p; p.read_flag = b->d_state.p; p.jobs = b->d_rescue_jobs.p; p.counts = b->d_state.p + state_counts(*b);
+  p.flagged = b->d_flagged.p; p.cap = b->rescue_cap;
+  ACCG_HIP(phmm_rescue_plan_launch(p, (uint32_t)b->regions_dev.size(), s));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
-  for (const KLaunch& l : b->launches) {
-    a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    ACCG_HIP(phmm_launch_rescue_f64(l.K, l.lpp, a, l.work0, l.n_work, b->ctx->stream));
+  a.work = b->d_rescue_jobs.p;
+  a.stream_cap = b->rescue_stream_cap; a.haps_cap = b->rescue_haps_cap;
+  static const int cls_lpp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 32, 64}, cls_k[PHMM_RESCUE_CLASSES] = {4, 8, 12, 16, 16, 16};
+  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
+    const uint32_t bound = std::min(b->rescue_bound[c], b->rescue_cap);
+    if (!bound) continue;
+    a.job_count = b->d_state.p + state_counts(*b) + c;
+    ACCG_HIP(phmm_launch_rescue_f64(cls_k[c], cls_lpp[c], a, (uint32_t)c * b->rescue_cap, bound, s));
   }
   return ACCG_OK;
 }
@@ -416,10 +456,16 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   if ((st = b->d_work.upload(b->work, s)) != ACCG_OK) return st;
   if ((st = b->d_out.alloc(b->pairs + 1)) != ACCG_OK) return st;
   if ((st = b->d_out64.alloc(b->pairs + 1)) != ACCG_OK) return st;
-  if ((st = b->d_nresc.alloc(1)) != ACCG_OK) return st;
+  b->rescue_cap = 0;
+  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b->rescue_cap = std::max(b->rescue_cap, b->rescue_bound[c]);
+  if ((st = b->d_regions.upload(b->regions_dev, s)) != ACCG_OK) return st;
+  if ((st = b->d_chunks.upload(b->chunks_dev, s)) != ACCG_OK) return st;
+  if ((st = b->d_sorted_reads.upload(b->sorted_reads, s)) != ACCG_OK) return st;
+  if ((st = b->d_flagged.alloc(b->rd.size() + 1)) != ACCG_OK) return st;
+  if ((st = b->d_state.alloc(state_words(*b))) != ACCG_OK) return st;
+  if ((st = b->d_rescue_jobs.alloc((size_t)b->rescue_cap * PHMM_RESCUE_CLASSES + 1)) != ACCG_OK) return st;
   ACCG_HIP(hipMemsetAsync(b->d_out.p, 0, (b->pairs + 1) * sizeof(float), s));
   ACCG_HIP(hipMemsetAsync(b->d_out64.p, 0, (b->pairs + 1) * sizeof(double), s));
-  ACCG_HIP(hipMemsetAsync(b->d_nresc.p, 0, sizeof(unsigned long long), s));
   ACCG_HIP(hipStreamSynchronize(s));   // the caller's host buffers may go away after this returns
   *out = b.release();
   return ACCG_OK;
@@ -491,7 +537,7 @@ extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, doubl
   ACCG_HIP(hipSetDevice(b->ctx->device));
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   unsigned long long nresc = 0;
-  ACCG_HIP(hipMemcpy(&nresc, b->d_nresc.p, sizeof nresc, hipMemcpyDeviceToHost));
+  ACCG_HIP(hipMemcpy(&nresc, b->d_state.p + state_nresc(*b), sizeof nresc, hipMemcpyDeviceToHost));
   std::vector<float> tmp;
   float* raw = out_raw;
   if (!raw && out_log10) { tmp.resize(b->pairs); raw = tmp.data(); }
@@ -516,7 +562,8 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   hipStreamSynchronize(b->ctx->stream);
   b->d_rblob.release(); b->d_hblob.release(); b->d_rd.release(); b->d_hp.release(); b->d_rd_out.release();
   b->d_hp_local.release(); b->d_hap_ids.release(); b->d_work.release(); b->d_out.release(); b->d_out64.release();
-  b->d_nresc.release();
+  b->d_regions.release(); b->d_chunks.release(); b->d_sorted_reads.release(); b->d_flagged.release();
+  b->d_state.release(); b->d_rescue_jobs.release();
   delete b;
 }
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr unsigned SLAB = QT * 1024;                 // bytes between two bases' tables
   const uint32_t job = blockIdx.x;
+  if (RESCUE && a.job_count && job >= *a.job_count) return;   // the grid is a host-side upper bound
   unsigned char* tab = smem;
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
   uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
@@ -298,7 +299,10 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     T acc_done = s.acc;
     column<STRICT, LPP>(s, d);
     if (rst) {
-      if (l == LPP - 1 && jl >= 0 && have) a.out[out_base + hcol[jl]] = acc_done;   // haplotype jl is complete
+      if (l == LPP - 1 && jl >= 0 && have) {                                         // haplotype jl is complete
+        a.out[out_base + hcol[jl]] = acc_done;
+        if (!RESCUE && sizeof(T) == 4 && a.read_flag && acc_done < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
+      }
       jl++;
       const T y0 = y0s[jl];
 #pragma unroll
@@ -338,7 +342,63 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
   return hipGetLastError();
 }
 
+// One workgroup per region: list the reads with an fp32 result below MIN_ACCEPTED (host_type.h:21), in the
+// region's length order, cut the list into wavefront-sized groups and emit (group x haplotype run) jobs into the
+// job array of the group's class.  The fp64 kernel then drops the haplotypes none of the group's reads needs.
+__global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
+  __shared__ uint32_t s_base, s_cnt;
+  __shared__ uint32_t s_wave[4];
+  const PhmmRegionDev R = p.regions[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  uint32_t* out = p.flagged + R.read0;
+  for (uint32_t i0 = 0; i0 < R.n_reads; i0 += 256) {          // ordered compaction, 256 reads at a time
+    const uint32_t i = i0 + tid;
+    bool f = false;
+    uint32_t rid = 0;
+    if (i < R.n_reads) {
+      rid = p.sorted_reads[R.read0 + i];
+      f = p.read_flag[rid] != 0;
+    }
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = s_base;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    if (f) out[before + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = rid;
+    __syncthreads();
+    if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  const uint32_t nf = s_base;
+  if (nf == 0) return;
+  // groups: the first (longest) read of a group decides its class; `per` reads per wavefront
+  for (uint32_t i = 0; i < nf;) {
+    int cls, lpp, K;
+    phmm_rescue_class(p.rd[out[i]].len, &cls, &lpp, &K);
+    const uint32_t per = 64u / (uint32_t)lpp;
+    if (tid == 0) s_cnt = atomicAdd(&p.counts[cls], R.n_chunks);
+    __syncthreads();
+    const uint32_t base = s_cnt;
+    for (uint32_t c = tid; c < R.n_chunks; c += 256) {
+      PhmmWork w;
+      for (uint32_t g = 0; g < 4; g++) w.read[g] = (g < per && i + g < nf) ? out[i + g] : PHMM_NO_READ;
+      w.hap_off = p.chunks[R.chunk0 + c].ids0; w.n_haps = p.chunks[R.chunk0 + c].n; w.pad_[0] = w.pad_[1] = 0;
+      if (base + c < p.cap) p.jobs[(size_t)cls * p.cap + base + c] = w;
+    }
+    __syncthreads();
+    i += per;
+  }
+}
+
 }  // namespace
+
+hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s) {
+  if (n_regions == 0) return hipSuccess;
+  hipLaunchKernelGGL(phmm_rescue_plan, dim3(n_regions), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
 
 hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
   return strict ? launch<float, true, false>(K, lpp, a, wb, n, s) : launch<float, false, false>(K, lpp, a, wb, n, s);
