@@ -134,6 +134,34 @@ void FalconPairHMM::computePairhmm(pairhmmInput* in, pairhmmOutput* out, bool& u
   if (!is_capability_error(st)) throw std::runtime_error(std::string("computePairhmm: ") + accg_strerror(st));
 }
 
+// ---- per-pair PairHMM ------------------------------------------------------------------------------------
+namespace {
+std::string one_read(const testcase* tc) {
+  read_t r = {tc->rslen, (char*)tc->rs, (char*)tc->q, (char*)tc->i, (char*)tc->d, (char*)tc->c};
+  return serialize(&r, 1);
+}
+std::string one_hap(const testcase* tc) { hap_t h = {tc->haplen, (char*)tc->hap}; return serialize(&h, 1); }
+float pair_f32(testcase* tc) {
+  std::string rs = one_read(tc), hs = one_hap(tc);
+  float raw = 0;
+  int st = accg_phmm_region(ctx(), rs.data(), rs.size(), hs.data(), hs.size(), ACCG_PHMM_FAST, &raw, nullptr, nullptr);
+  if (st != ACCG_OK) throw std::runtime_error(std::string("compute_fp_avxs: ") + accg_strerror(st));
+  return raw;
+}
+}  // namespace
+extern "C" int accg_phmm_region_f64(accg_ctx*, const void*, size_t, const void*, size_t, double*);
+namespace {
+double pair_f64(testcase* tc) {
+  std::string rs = one_read(tc), hs = one_hap(tc);
+  double raw = 0;
+  int st = accg_phmm_region_f64(ctx(), rs.data(), rs.size(), hs.data(), hs.size(), &raw);
+  if (st != ACCG_OK) throw std::runtime_error(std::string("compute_fp_avxd: ") + accg_strerror(st));
+  return raw;
+}
+}  // namespace
+float (*compute_fp_avxs)(testcase*) = &pair_f32;
+double (*compute_fp_avxd)(testcase*) = &pair_f64;
+
 // ---- HTC Smith-Waterman -------------------------------------------------------------------------------
 namespace {
 // one ref x B alts -> CIGARs; returns device ns, or -1 when the device cannot take the batch
@@ -172,6 +200,17 @@ double sw_batch(const char* ref, int refLength, const char* alts, size_t alt_str
   return (double)ms * 1e6;
 }
 }  // namespace
+
+namespace {
+int32_t one_pair_sw(int32_t match, int32_t mismatch, int32_t open, int32_t extend, uint8_t* seq1, uint8_t* seq2, int32_t len1,
+                    int32_t len2, int8_t strategy, struct Cigar* cigarRet) {
+  int off = 0, al = len2;
+  if (sw_batch((const char*)seq1, len1, (const char*)seq2, 0, &al, 1, strategy, match, mismatch, open, extend, cigarRet, &off) < 0)
+    throw std::runtime_error("runSWOnePairBT: pair outside the device limits");
+  return off;
+}
+}  // namespace
+int32_t (*runSWOnePairBT_fp_avx2)(int32_t, int32_t, int32_t, int32_t, uint8_t*, uint8_t*, int32_t, int32_t, int8_t, struct Cigar*) = &one_pair_sw;
 
 bool FalconSWFPGA_init(char*) { try { ctx(); return true; } catch (const std::exception&) { return false; } }
 void FalconSWFPGA_release() {}

@@ -61,6 +61,14 @@ class FalconPairHMM {
   double kernel_ns_;
 };
 
+// ---- per-pair entry points ------------------------------------------------------------------------
+// testcase + compute_fp_avxs / compute_fp_avxd (pairhmm/xlnx/host/host_type.h:69-73, avx_impl.h:5-6): raw likelihood
+// x 2^120 / x 2^1020 of ONE pair.  A device call per pair is only meant for callers that are written that way; batches
+// belong in compute_fpga / FalconPairHMM.
+typedef struct { int rslen, haplen; const char *q, *i, *d, *c; const char *hap, *rs; } testcase;
+extern float (*compute_fp_avxs)(testcase*);
+extern double (*compute_fp_avxd)(testcase*);
+
 // ---- HTC Smith-Waterman ---------------------------------------------------------------------------
 #define MAX_SEQ_LENGTH 1536
 #define MAX_BATCH_SIZE 260
@@ -90,5 +98,8 @@ void FalconSWFPGA_release();
 // [0..1] total length (32 bit), [2..2+B) element counts, then per alt (len,state)* in reverse order + alignment_offset.
 void _smithWatermanRun(char* inputs, int refLength, int batchSize, int overhang_strategy, int w_match, int w_mismatch,
                        int w_open, int w_extend, short* outputs);
+// runSWOnePairBT_fp_avx2 (htc-sw/intel_avx/avx2_impl.h:6): one pair, returns alignment_offset, CIGAR in *cigarRet
+extern int32_t (*runSWOnePairBT_fp_avx2)(int32_t match, int32_t mismatch, int32_t open, int32_t extend, uint8_t* seq1, uint8_t* seq2,
+                                         int32_t len1, int32_t len2, int8_t overhangStrategy, struct Cigar* cigarRet);
 int SWPairwiseAlignmentMultiBatch(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int batchSize, int* altLengths,
                                   struct Cigar* cigarResults, int* alignmentOffsets, int overhang_strategy, int option);

@@ -567,6 +567,20 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   delete b;
 }
 
+// One region entirely in fp64 (the reference's compute_fp_avxd per pair / use_double = true): raw likelihood x 2^1020.
+extern "C" int accg_phmm_region_f64(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
+                                    double* out_raw64) {
+  accg_phmm_batch* b = nullptr;
+  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
+  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
+  int st = accg_phmm_batch_create(ctx, 1, rs, rb, hs, hb, &b);
+  if (st != ACCG_OK) return st;
+  st = accg_phmm_batch_run_f64(b);
+  if (st == ACCG_OK) st = accg_phmm_batch_results_f64(b, out_raw64);
+  accg_phmm_batch_destroy(b);
+  return st;
+}
+
 extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
                                 size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* cnt) {
   accg_phmm_batch* b = nullptr;

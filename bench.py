@@ -163,11 +163,13 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
         b.cigars()
         cigar_ms = (time.perf_counter() - tc0) / 2 * 1e3
         ach = b.algorithmic_bytes / (k_ms * 1e-3) / 1e9
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        sw_traffic = json.load(open(tr)).get("sw_c2", {}).get("hbm_bytes_per_launch") if os.path.exists(tr) else None
         extras = {"kernel_ms": k_ms, "pairs_per_gpu": b.n, "cells_per_gpu": b.cells,
                   "with_cigar": {"ms_per_step": cigar_ms, "value": b.cells / (cigar_ms * 1e-3) / 1e9, "unit": "GCUPS",
                                  "note": "fill + backtrace + D2H of 48-element CIGAR slots, wall clock"},
                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
+                               "traffic": sw_traffic, "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": b.algorithmic_bytes,
                                "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
                                         "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
@@ -261,9 +263,9 @@ def main():
                 "algorithmic_bytes_per_launch": algo,
                 "valu": {"achieved_tflops": flops / 1e12, "peak_tflops": 157.3, "frac": flops / 157.3e12,
                          "note": "12 algorithmic flop/cell (baseline_impl.cpp:84-86); the recurrence is VALU-issue bound, not HBM bound"}}
-        tr = os.path.join(ROOT, "profiles", "traffic_phmm_c1.json")
+        tr = os.path.join(ROOT, "profiles", "traffic.json")     # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
         if os.path.exists(tr):
-            roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+            roof["traffic"] = json.load(open(tr)).get("phmm_c1", {}).get("hbm_bytes_per_launch")
         cpu = None if args.no_cpu_baseline else cpu_baseline_phmm(reads, haps)
         line = {
             "metric": "pairhmm_forward_gcups_fp32", "value": total_cells / wall / 1e9, "unit": "GCUPS",

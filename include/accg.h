@@ -72,6 +72,18 @@ int accg_device_name(accg_ctx* ctx, char* buf, size_t n);
 int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
                      size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* counters);
 
+/* The same region entirely in fp64 (compute_fp_avxd, avx_impl.h:6; use_double, FalconPairHMM.cpp:82): raw x 2^1020. */
+int accg_phmm_region_f64(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
+                         double* out_raw64);
+int accg_phmm_batch_run_f64(accg_phmm_batch* b);
+int accg_phmm_batch_results_f64(accg_phmm_batch* b, double* out_raw64);
+/* fp32 pass only / whole run timing with hipEvents on the launch stream; what: 0 = fp32 + rescue, 1 = fp32 pass only */
+int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int warmup, int iters, float* ms_per_run);
+uint64_t accg_phmm_batch_jobs(const accg_phmm_batch* b);
+/* Context<float>/<double> tables as uploaded (ph2pr[128], matchToMatchProb[8256], INITIAL_CONSTANT, its log10) */
+void accg_phmm_tables_f32(float* ph2pr, float* m2m, float* init, float* log10_init);
+void accg_phmm_tables_f64(double* ph2pr, double* m2m, double* init, double* log10_init);
+
 /* Device-resident multi-region batch: upload once, run many times (pipelines, bench.py).
  * Regions are independent; outputs are concatenated in region order, each region row-major. */
 int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* const* reads_ser, const size_t* reads_bytes,

@@ -61,6 +61,15 @@ static int test_pairhmm() {
         if (f > 1e-27f && !(fabs((fr - f) / f) <= 1e-5)) { if (bad < 5) printf("compute_fpga raw %d,%d: %g vs %g\n", i, j, fr, f); bad++; }
       }
   }
+  {   // per-pair entry points (avx_impl.h:5-6): fp32 and fp64 raw values of single pairs
+    const char* rs = "ACGTACGTTAGCAGCATCGATCGACTAGCTA"; const char* hp = "TTACGTACGTTAGCTGCATCGATCGACTAGCTAGG";
+    std::string q(31, (char)30), qi(31, (char)40), qd(31, (char)40), qc(31, (char)10);
+    testcase tc = {31, 35, q.data(), qi.data(), qd.data(), qc.data(), hp, rs};
+    float f = compute_fp_avxs(&tc); double d = compute_fp_avxd(&tc);
+    float wf = orc_phmm_forward_f32(31, 35, rs, q.data(), qi.data(), qd.data(), qc.data(), hp, 0);
+    double wd = orc_phmm_forward_f64(31, 35, rs, q.data(), qi.data(), qd.data(), qc.data(), hp, 0);
+    if (!(fabs((f - wf) / wf) <= 1e-5) || d != wd) { printf("per-pair: %g vs %g, %.17g vs %.17g\n", f, wf, d, wd); bad++; }
+  }
   printf("pairhmm: %s (kernel %.0f ns, peak %.1f GCUPS)\n", bad ? "FAILED" : "ok", falcon.get_kernel_time(), peak_kernel_gcups);
   return bad;
 }
@@ -110,6 +119,12 @@ static int test_sw() {
         if (((int)(unsigned short)out[0] | ((int)out[1] << 16)) != ptr) bad++;
       }
     }
+  {   // per-pair entry point (intel_avx/avx2_impl.h:6)
+    const char* r = "ACGTACGTTAGCAGCATCGATCGACTAGCTAGGATCGATTTAGC"; const char* a = "ACGTACGTTAGCAGCTTCGATCGACTAGCTAGGATCGA";
+    static struct Cigar c1;
+    int off = runSWOnePairBT_fp_avx2(w[0], w[1], w[2], w[3], (uint8_t*)r, (uint8_t*)a, (int)strlen(r), (int)strlen(a), 0, &c1);
+    if (cmp_cigar(c1, off, r, (int)strlen(r), a, (int)strlen(a), 0, w)) { printf("runSWOnePairBT mismatch\n"); bad++; }
+  }
   FalconSWFPGA_release();
   printf("htc-sw: %s\n", bad ? "FAILED" : "ok");
   return bad;
