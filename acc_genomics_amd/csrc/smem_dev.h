@@ -1,0 +1,25 @@
+// Device/host shared declarations for the SMEM seeding kernel (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace accg {
+
+struct alignas(16) SmemIntv { uint64_t x0, x1, x2, info; };   // bwtintv_t: {x[0], x[1], x[2], info}
+
+struct SmemArgs {
+  const uint32_t* bwt;          // BWA block layout, 64 B per 128 symbols (smem/host/baseline.cpp:26-37)
+  uint64_t primary, L2[5];
+  const uint8_t* seq;           // n_reads x seq_stride codes (0-3, >= 4 ambiguous)
+  const uint8_t* seq_len;
+  uint32_t seq_stride, n_reads;
+  SmemIntv* out;                // n_reads x max_out
+  int32_t* mem_num;             // uncapped interval count per read
+  uint32_t max_out;
+  SmemIntv* scratch;            // 2 x 256 intervals per thread, interleaved: element e of thread t at [e * n_threads + t]
+  uint32_t n_threads;
+};
+
+hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s);
+
+}  // namespace accg

@@ -1,0 +1,115 @@
+// Host side of the SMEM seeding path: index upload (the role of ocl_init, smem/host/ocl.cpp:169-293) and read batches
+// (smem_ocl / ocl_kernel_invoke, :296-418).
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include "accg_internal.h"
+#include "smem_dev.h"
+
+using namespace accg;
+
+struct accg_smem_index {
+  accg_ctx* ctx = nullptr;
+  uint32_t* d_bwt = nullptr;
+  uint64_t words = 0, primary = 0, L2[5] = {0};
+};
+
+struct accg_smem_batch {
+  accg_smem_index* idx = nullptr;
+  uint32_t n = 0, stride = 0, max_out = 0, slice = 0;
+  uint8_t *d_seq = nullptr, *d_len = nullptr;
+  SmemIntv *d_out = nullptr, *d_scratch = nullptr;
+  int32_t* d_num = nullptr;
+  uint64_t bases = 0;
+};
+
+extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para,
+                                      accg_smem_index** out) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out || !bwt || !bwt_para || bwt_words == 0 || bwt_words % 16) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<accg_smem_index> x(new accg_smem_index);
+  x->ctx = ctx; x->words = bwt_words; x->primary = bwt_para[0];
+  for (int c = 0; c < 5; c++) x->L2[c] = bwt_para[1 + c];
+  ACCG_HIP(hipMalloc((void**)&x->d_bwt, bwt_words * 4));
+  ACCG_HIP(hipMemcpy(x->d_bwt, bwt, bwt_words * 4, hipMemcpyHostToDevice));
+  *out = x.release();
+  return ACCG_OK;
+}
+extern "C" void accg_smem_index_destroy(accg_smem_index* x) {
+  if (!x) return;
+  hipSetDevice(x->ctx->device);
+  hipStreamSynchronize(x->ctx->stream);
+  if (x->d_bwt) hipFree(x->d_bwt);
+  delete x;
+}
+
+extern "C" int accg_smem_batch_create(accg_smem_index* idx, const uint8_t* seq, uint32_t seq_stride, const uint8_t* seq_len,
+                                      uint32_t n_reads, uint32_t max_out, accg_smem_batch** out) {
+  if (!idx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out || (n_reads && (!seq || !seq_len)) || max_out == 0 || seq_stride == 0) return ACCG_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n_reads; i++) if (seq_len[i] > seq_stride) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(idx->ctx->device));
+  std::unique_ptr<accg_smem_batch> b(new accg_smem_batch);
+  b->idx = idx; b->n = n_reads; b->stride = seq_stride; b->max_out = max_out;
+  b->slice = std::min<uint32_t>(std::max<uint32_t>(n_reads, 64), 262144);   // 512 x 32 B of scratch per resident read
+  const size_t n1 = std::max<uint32_t>(n_reads, 1);
+  ACCG_HIP(hipMalloc((void**)&b->d_seq, n1 * seq_stride));
+  ACCG_HIP(hipMalloc((void**)&b->d_len, n1));
+  ACCG_HIP(hipMalloc((void**)&b->d_out, n1 * max_out * sizeof(SmemIntv)));
+  ACCG_HIP(hipMalloc((void**)&b->d_num, n1 * sizeof(int32_t)));
+  ACCG_HIP(hipMalloc((void**)&b->d_scratch, (size_t)b->slice * 512 * sizeof(SmemIntv)));
+  if (n_reads) {
+    ACCG_HIP(hipMemcpy(b->d_seq, seq, (size_t)n_reads * seq_stride, hipMemcpyHostToDevice));
+    ACCG_HIP(hipMemcpy(b->d_len, seq_len, n_reads, hipMemcpyHostToDevice));
+    for (uint32_t i = 0; i < n_reads; i++) b->bases += seq_len[i];
+  }
+  *out = b.release();
+  return ACCG_OK;
+}
+extern "C" uint64_t accg_smem_batch_bases(const accg_smem_batch* b) { return b ? b->bases : 0; }
+
+extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  accg_smem_index* x = b->idx;
+  ACCG_HIP(hipSetDevice(x->ctx->device));
+  SmemArgs a;
+  a.bwt = x->d_bwt; a.primary = x->primary;
+  for (int c = 0; c < 5; c++) a.L2[c] = x->L2[c];
+  a.seq = b->d_seq; a.seq_len = b->d_len; a.seq_stride = b->stride; a.n_reads = b->n;
+  a.out = b->d_out; a.mem_num = b->d_num; a.max_out = b->max_out; a.scratch = b->d_scratch; a.n_threads = b->slice;
+  for (uint32_t r0 = 0; r0 < b->n; r0 += b->slice)
+    ACCG_HIP(smem_launch(a, r0, std::min(b->slice, b->n - r0), x->ctx->stream));
+  return ACCG_OK;
+}
+extern "C" int accg_smem_batch_time(accg_smem_batch* b, int warmup, int iters, float* ms_per_run) {
+  if (!b || !ms_per_run || iters <= 0 || warmup < 0) return ACCG_ERR_BAD_ARG;
+  accg_ctx* c = b->idx->ctx;
+  int st;
+  for (int i = 0; i < warmup; i++) if ((st = accg_smem_batch_run(b)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < iters; i++) if ((st = accg_smem_batch_run(b)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
+  ACCG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_run = ms / iters;
+  return ACCG_OK;
+}
+extern "C" int accg_smem_batch_results(accg_smem_batch* b, void* mem_output, int32_t* mem_num) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->idx->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->idx->ctx->stream));
+  if (b->n) {
+    if (mem_output) ACCG_HIP(hipMemcpy(mem_output, b->d_out, (size_t)b->n * b->max_out * sizeof(SmemIntv), hipMemcpyDeviceToHost));
+    if (mem_num) ACCG_HIP(hipMemcpy(mem_num, b->d_num, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return ACCG_OK;
+}
+extern "C" void accg_smem_batch_destroy(accg_smem_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->idx->ctx->device);
+  hipStreamSynchronize(b->idx->ctx->stream);
+  for (void* p : {(void*)b->d_seq, (void*)b->d_len, (void*)b->d_out, (void*)b->d_num, (void*)b->d_scratch}) if (p) hipFree(p);
+  delete b;
+}

@@ -68,6 +68,15 @@ def load():
     L.accg_sw_batch_destroy.argtypes = [vp]
     L.accg_sw_batch_run_cigar.argtypes = [vp, C.c_int]
     L.accg_sw_batch_cigars.argtypes = [vp, vp, vp, vp]
+    L.accg_smem_index_create.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(vp)]
+    L.accg_smem_index_destroy.argtypes = [vp]
+    L.accg_smem_batch_create.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.accg_smem_batch_bases.restype = C.c_uint64
+    L.accg_smem_batch_bases.argtypes = [vp]
+    L.accg_smem_batch_run.argtypes = [vp]
+    L.accg_smem_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.accg_smem_batch_results.argtypes = [vp, vp, vp]
+    L.accg_smem_batch_destroy.argtypes = [vp]
     L.accg_phmm_tables_f32.argtypes = [vp, vp, vp, vp]
     L.accg_phmm_tables_f64.argtypes = [vp, vp, vp, vp]
     _lib = L
@@ -221,6 +230,66 @@ class SwBatch:
     def close(self):
         if self.h:
             self.L.accg_sw_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class SmemIndex:
+    """FM-index resident on the device (accg_smem_index_*)."""
+
+    def __init__(self, ctx, bwt_words, para):
+        self.ctx, self.L = ctx, ctx.L
+        self.bwt = np.ascontiguousarray(bwt_words, dtype=np.uint32)
+        self.para = np.ascontiguousarray(para, dtype=np.uint64)
+        self.h = C.c_void_p()
+        _check(self.L.accg_smem_index_create(ctx.h, self.bwt.ctypes.data, len(self.bwt), self.para.ctypes.data, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.accg_smem_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class SmemBatch:
+    """Device-resident batch of reads (accg_smem_batch_*): seq uint8[n, stride] base codes, seq_len uint8[n]."""
+
+    def __init__(self, index, seq, seq_len, max_out=256):
+        self.L = index.L
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ln = np.ascontiguousarray(seq_len, dtype=np.uint8)
+        self.n, self.max_out = int(len(ln)), int(max_out)
+        self.h = C.c_void_p()
+        _check(self.L.accg_smem_batch_create(index.h, seq.ctypes.data, seq.shape[1], ln.ctypes.data, self.n, self.max_out, C.byref(self.h)))
+        self.bases = int(self.L.accg_smem_batch_bases(self.h))
+
+    def run(self):
+        _check(self.L.accg_smem_batch_run(self.h))
+
+    def time(self, warmup=1, iters=3):
+        ms = C.c_float()
+        _check(self.L.accg_smem_batch_time(self.h, warmup, iters, C.byref(ms)))
+        return ms.value
+
+    def results(self):
+        out = np.zeros((self.n, self.max_out, 4), np.uint64)
+        num = np.zeros(self.n, np.int32)
+        _check(self.L.accg_smem_batch_results(self.h, out.ctypes.data, num.ctypes.data))
+        return out, num
+
+    def close(self):
+        if self.h:
+            self.L.accg_smem_batch_destroy(self.h)
             self.h = C.c_void_p()
 
     def __enter__(self):

@@ -129,6 +129,26 @@ int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el);
 int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* alignment_offsets, int32_t* elements);
 void accg_sw_batch_destroy(accg_sw_batch* b);
 
+/* ---- SMEM seeding (BWA-MEM, configs[4]) -----------------------------------------------------------------
+ * mem_collect_intv_new of the reference (smem/host/baseline.cpp:387-422) for batches of reads against an FM-index in
+ * BWA's block layout.  accg_smem_index_create plays the role of ocl_init (smem/host/ocl.h:29): the index is uploaded
+ * once; bwt_para = {primary, L2[0..4], ...} as smem/main.cpp:221 builds it.  A batch is smem_ocl's input
+ * (smem/host/ocl.h:30-32): seq = n x seq_stride base codes (0-3, >= 4 ambiguous), seq_len uint8 per read; outputs
+ * mem_output = n x max_out intervals {x[0], x[1], x[2], info} (bwtintv_t, 32 B) in the order the CPU code produces them
+ * and mem_num = the uncapped count (a count > max_out means "redo on the CPU", smem/main.cpp:159-164).
+ * PARITY of this path is unpinned: the reference file needs libbwa and cannot be built here. */
+typedef struct accg_smem_index accg_smem_index;
+typedef struct accg_smem_batch accg_smem_batch;
+int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para, accg_smem_index** out);
+void accg_smem_index_destroy(accg_smem_index* idx);
+int accg_smem_batch_create(accg_smem_index* idx, const uint8_t* seq, uint32_t seq_stride, const uint8_t* seq_len, uint32_t n_reads,
+                           uint32_t max_out, accg_smem_batch** out);
+uint64_t accg_smem_batch_bases(const accg_smem_batch* b);
+int accg_smem_batch_run(accg_smem_batch* b);
+int accg_smem_batch_time(accg_smem_batch* b, int warmup, int iters, float* ms_per_run);
+int accg_smem_batch_results(accg_smem_batch* b, void* mem_output, int32_t* mem_num);
+void accg_smem_batch_destroy(accg_smem_batch* b);
+
 /* ---- counters (multi-GPU) ---------------------------------------------------------------------
  * Packs counters into the uint64[4] {cells, pairs, kernel_ns, rescued} vector that the ranks
  * all-reduce over RCCL; the collective itself is issued by the host harness

@@ -72,6 +72,11 @@ void orc_sw_score_many(const char* refs, int ref_stride, const int* refLens, con
                        const int* altLens, int n, int strategy, int w_match, int w_mismatch, int w_open,
                        int w_extend, int* score, int* p1, int* p2, int n_threads);
 
+/* ---- SMEM seeding (PARITY UNPINNED, see smem_oracle.c) ------------------------------------------------------- */
+void orc_smem_batch(const uint32_t* bwt, const uint64_t* para, const uint8_t* seq, int seq_stride, const uint8_t* seq_len,
+                    int batch, int max_out, uint64_t* out, int* mem_num, int n_threads);
+void orc_smem_occ4(const uint32_t* bwt, const uint64_t* para, uint64_t k, uint64_t cnt[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+"""SMEM seeding on the GPU through the C ABI, bit-exact against oracle/smem_oracle.c (whose own pin is brute force,
+tests/test_smem_oracle.py: the reference's baseline.cpp cannot be built here)."""
+import numpy as np
+import pytest
+
+import orc
+import acc_genomics_amd as A
+from acc_genomics_amd import fmindex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = A.Context(0)
+    yield c
+    c.close()
+
+
+def _reads(rng, g, n, rlen, sub=0.02, amb=0.2):
+    out = []
+    for _ in range(n):
+        ln = int(rng.integers(rlen[0], rlen[1] + 1))
+        off = int(rng.integers(0, len(g) - ln))
+        r = g[off:off + ln].copy()
+        if rng.random() < 0.5:
+            r = fmindex.revcomp_codes(r)
+        m = rng.random(ln) < sub
+        r[m] = rng.integers(0, 4, size=int(m.sum()))
+        if rng.random() < amb:
+            r[int(rng.integers(0, ln))] = 4
+        out.append(r)
+    return out
+
+
+def _oracle(bwt, para, seq, ln, max_out):
+    O = orc.oracle()
+    n = len(ln)
+    out = np.zeros((n, max_out, 4), np.uint64)
+    num = np.zeros(n, np.int32)
+    O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, seq.shape[1], ln.ctypes.data, n, max_out, out.ctypes.data,
+                     num.ctypes.data, 8)
+    return out, num
+
+
+@pytest.mark.parametrize("seed,glen,repeat", [(11, 4000, False), (12, 30000, True), (13, 200000, True)])
+def test_bit_exact_vs_oracle(ctx, seed, glen, repeat):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=glen).astype(np.uint8)
+    if repeat:
+        for _ in range(20):
+            a, b = rng.integers(0, glen - 200, size=2)
+            g[b:b + 150] = g[a:a + 150]
+    bwt, para, _ = fmindex.build(g)
+    reads = _reads(rng, g, 700, (1, 255)) + _reads(rng, g, 300, (150, 150), sub=0.01, amb=0.0)
+    reads.append(np.full(40, 4, np.uint8))             # all ambiguous
+    reads.append(rng.integers(0, 4, size=100).astype(np.uint8))   # unrelated
+    seq, ln = fmindex.encode_reads(reads)
+    want, wnum = _oracle(bwt, para, seq, ln, 256)
+    with A.SmemIndex(ctx, bwt, para) as idx:
+        with A.SmemBatch(idx, seq, ln, 256) as b:
+            b.run()
+            got, gnum = b.results()
+            b.run()
+            got2, gnum2 = b.results()
+    assert np.array_equal(gnum, wnum)
+    assert gnum.max() <= 256 and gnum.sum() > 500
+    for k in range(len(reads)):
+        assert np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]), k
+    assert np.array_equal(gnum, gnum2) and np.array_equal(got, got2)
+
+
+def test_small_output_slot_counts_but_does_not_store(ctx):
+    rng = np.random.default_rng(21)
+    g = rng.integers(0, 4, size=20000).astype(np.uint8)
+    bwt, para, _ = fmindex.build(g)
+    reads = _reads(rng, g, 200, (120, 200), sub=0.05, amb=0.0)
+    seq, ln = fmindex.encode_reads(reads)
+    want, wnum = _oracle(bwt, para, seq, ln, 256)
+    with A.SmemIndex(ctx, bwt, para) as idx:
+        with A.SmemBatch(idx, seq, ln, 2) as b:
+            b.run()
+            got, gnum = b.results()
+    # with a slot of 2 the re-seeding pass only sees the first two SMEMs, so counts can only be <= the full run's
+    assert (gnum <= wnum).all() and (gnum >= np.minimum(wnum, 2)).all()
+    for k in range(len(reads)):
+        assert np.array_equal(got[k, :min(2, gnum[k])], want[k, :min(2, gnum[k])])
