@@ -104,7 +104,7 @@ float* compute_fpga(const char*, std::string read_data, std::string hap_data, ui
   }
   return g_ret;
 }
-void cleanup() { if (g_ctx) accg_shutdown(g_ctx); g_ctx = nullptr; free(g_ret); g_ret = nullptr; g_ret_n = 0; }
+void cleanup() { ocl_release(); if (g_ctx) accg_shutdown(g_ctx); g_ctx = nullptr; free(g_ret); g_ret = nullptr; g_ret_n = 0; }
 
 // ---- FalconPairHMM ----------------------------------------------------------------------------------
 FalconPairHMM::FalconPairHMM() : ctx_(nullptr), kernel_ns_(0) {
@@ -161,6 +161,32 @@ double pair_f64(testcase* tc) {
 }  // namespace
 float (*compute_fp_avxs)(testcase*) = &pair_f32;
 double (*compute_fp_avxd)(testcase*) = &pair_f64;
+
+// ---- SMEM -----------------------------------------------------------------------------------------------
+namespace { accg_smem_index* g_smem = nullptr; uint64_t g_smem_words = 0; }
+void ocl_init(char*, const uint32_t* bwt, const uint64_t* bwt_para, uint64_t bwt_size, bwtintv_t*, int) {
+  if (g_smem) { accg_smem_index_destroy(g_smem); g_smem = nullptr; }
+  // bwt_size counts uint32 words of the block layout (smem/main.cpp:221 passes ceil(bwt_size/16) blocks in bwt_para[6])
+  const uint64_t words = (bwt_size + 15) / 16 * 16;
+  int st = accg_smem_index_create(ctx(), bwt, words, bwt_para, &g_smem);
+  if (st != ACCG_OK) throw std::runtime_error(std::string("ocl_init: ") + accg_strerror(st));
+  g_smem_words = words;
+}
+int smem_ocl(char*, const uint32_t*, const uint64_t*, uint8_t* seq, uint8_t* seq_len, int batch_size, bwtintv_t* mem_output,
+             int* mem_num, double kernel_time[BANK_NUM]) {
+  if (!g_smem) throw std::runtime_error("smem_ocl: ocl_init was not called");
+  accg_smem_batch* b = nullptr;
+  int st = accg_smem_batch_create(g_smem, seq, SEQ_LENGTH, seq_len, (uint32_t)batch_size, MAX_INTV_ALLOC, &b);
+  if (st != ACCG_OK) throw std::runtime_error(std::string("smem_ocl: ") + accg_strerror(st));
+  float ms = 0;
+  st = accg_smem_batch_time(b, 0, 1, &ms);
+  if (st == ACCG_OK) st = accg_smem_batch_results(b, mem_output, mem_num);
+  accg_smem_batch_destroy(b);
+  if (st != ACCG_OK) throw std::runtime_error(std::string("smem_ocl: ") + accg_strerror(st));
+  for (int i = 0; i < BANK_NUM; i++) kernel_time[i] = (double)ms * 1e6;
+  return 0;
+}
+void ocl_release() { if (g_smem) accg_smem_index_destroy(g_smem); g_smem = nullptr; }
 
 // ---- HTC Smith-Waterman -------------------------------------------------------------------------------
 namespace {

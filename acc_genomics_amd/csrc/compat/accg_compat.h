@@ -8,6 +8,7 @@
 //   FalconSWFPGA_init / _run / _release                                htc-sw/host/FalconSW_FPGA.cpp:16,28,92
 //   _smithWatermanRun (byte contract of the FPGA kernel)               htc-sw/host/smithWatermanHost.h:14, FalconSW_FPGA.cpp:53-88
 //   SWPairwiseAlignmentMultiBatch                                      htc-sw/host/FalconSW_AVX.cpp:304
+//   ocl_init / smem_ocl                                                smem/host/ocl.h:29-32
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
@@ -68,6 +69,20 @@ class FalconPairHMM {
 typedef struct { int rslen, haplen; const char *q, *i, *d, *c; const char *hap, *rs; } testcase;
 extern float (*compute_fp_avxs)(testcase*);
 extern double (*compute_fp_avxd)(testcase*);
+
+// ---- SMEM seeding (smem/host/ocl.h:29-32) ----------------------------------------------------------------
+typedef uint64_t bwtint_t;
+typedef struct { bwtint_t x[3], info; } bwtintv_t;     // libbwa's bwt.h type the reference uses for intervals
+#define BANK_NUM 4            /* smem/Makefile:20 */
+#define MAX_INTV_ALLOC 256    /* smem/common/common.h:39 */
+#define SEQ_LENGTH 256        /* smem/common/common.h:41 */
+// Uploads the index once (the reference replicates it per DDR bank here).  btsm (bitstream path) and mem are unused.
+void ocl_init(char* btsm, const uint32_t* bwt, const uint64_t* bwt_para, uint64_t bwt_size, bwtintv_t* mem, int batch_size);
+// seq: batch x SEQ_LENGTH base codes, seq_len: uint8 per read; mem_output: batch x MAX_INTV_ALLOC intervals, mem_num: counts.
+// kernel_time[BANK_NUM] receives the device ns (same value in every slot).  Returns 0.
+int smem_ocl(char* btsm, const uint32_t* bwt, const uint64_t* bwt_para, uint8_t* seq, uint8_t* seq_len, int batch_size,
+             bwtintv_t* mem_output, int* mem_num, double kernel_time[BANK_NUM]);
+void ocl_release();
 
 // ---- HTC Smith-Waterman ---------------------------------------------------------------------------
 #define MAX_SEQ_LENGTH 1536

@@ -2,7 +2,7 @@
 //
 // What it computes: mem_collect_intv_new of the reference (smem/host/baseline.cpp:387-422) = bwt_smem1a_new
 // (:180-304) over the read, re-seeding inside long low-occurrence SMEMs, and the LAST-like bwt_seed_strategy1 pass
-// (:306-327), on top of bwt_extend / bwt_occ4 (:17-100).  PARITY: bit-exact with oracle/smem_oracle.c, which restates
+// (:306-327), on top of bwt_extend / bwt_occ4 (:17-100).  PARITY: bit-exact with the CPU restatement kept with the tests (smem_oracle.c), which restates
 // those functions; the reference file itself cannot be built here (libbwa is not in the tree), see DESIGN.md.
 //
 // Why one thread per read: every bwt_extend depends on the previous one and costs two random 64-byte block reads, so

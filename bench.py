@@ -179,6 +179,69 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
     return cells, t1 - t0, extras
 
 
+def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
+    """SMEM leg: configs[4], n_reads x 150 bp (1 % substitutions, both strands) against the 64 MB BWT of a random genome."""
+    import acc_genomics_amd as A
+    from acc_genomics_amd import fmindex, synth
+    rng = synth.rng_for(4 + 1000 * rank)
+    g = rng.integers(0, 4, size=genome_bp).astype(np.uint8)
+    bwt, para, _ = fmindex.build(g, device="cuda")        # setup: suffix array by prefix doubling on the GPU (torch)
+    offs = rng.integers(0, genome_bp - 150, size=n_reads)
+    reads = g[offs[:, None] + np.arange(150)[None, :]]
+    flip = rng.random(n_reads) < 0.5
+    reads[flip] = 3 - reads[flip][:, ::-1]
+    m = rng.random(reads.shape) < 0.01
+    reads[m] = rng.integers(0, 4, size=int(m.sum()))
+    seq = np.zeros((n_reads, 256), np.uint8)
+    seq[:, :150] = reads
+    ln = np.full(n_reads, 150, np.uint8)
+    idx = A.SmemIndex(ctx, bwt, para)
+    b = A.SmemBatch(idx, seq, ln, 64)
+    b.run()
+    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h))
+    stream.synchronize(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    stream.synchronize(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    extras = None
+    if rank == 0:
+        import orc
+        k_ms = b.time(warmup=0, iters=max(2, steps))
+        O = orc.oracle()
+        S = 8192
+        wout = np.zeros((S, 64, 4), np.uint64); wnum = np.zeros(S, np.int32)
+        th = host_cores()
+        O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, S, 64, wout.ctypes.data, wnum.ctypes.data, th)
+        lookups_per_read = O.orc_smem_last_lookups() / S
+        algo = lookups_per_read * n_reads * 64.0            # 64-byte index blocks requested (SURVEY.md 8d)
+        cpu = None
+        if with_cpu:
+            c0, reps = time.perf_counter(), 0
+            while time.perf_counter() - c0 < 1.0:
+                O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, S, 64, wout.ctypes.data, wnum.ctypes.data, th)
+                reps += 1
+            dt = time.perf_counter() - c0
+            cpu = {"value": S * reps / dt / 1e6, "unit": "Mreads/s", "cores": th, "kind": "port",
+                   "sample": "%d x %d reads through oracle/smem_oracle.c (restatement of smem/host/baseline.cpp; the reference file "
+                             "itself needs libbwa and cannot be built), %.2f s wall" % (reps, S, dt)}
+        ach = algo / (k_ms * 1e-3) / 1e9
+        extras = {"kernel_ms": k_ms, "reads_per_gpu": n_reads, "index_mb": int(bwt.nbytes >> 20), "block_lookups_per_read": lookups_per_read,
+                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "smem_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
+                               "note": "64-byte index block per Occ lookup; the 64 MB index is served from L2 / Infinity Cache, the path is "
+                                       "bound by dependent-lookup latency"},
+                  "cpu_baseline": cpu}
+    reads_done = n_reads * steps
+    b.close(); idx.close()
+    return reads_done, t1 - t0, extras
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +250,7 @@ def main():
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sw-steps", type=int, default=5, help="passes over the Smith-Waterman batch (0 = skip that leg)")
+    ap.add_argument("--smem-steps", type=int, default=3, help="passes over the SMEM read batch (0 = skip that leg)")
     args = ap.parse_args()
 
     import torch
@@ -249,6 +313,21 @@ def main():
                                          "SOFTCLIP/IGNORE halves, weights 200/-150/-260/-11, score + end cell"}}
             sw.update(sw_extras)
 
+    smem = None
+    if args.smem_steps > 0:
+        sm_reads, sm_t, sm_extras = bench_smem(ctx, rank, dist, torch, args.smem_steps, not args.no_cpu_baseline)
+        v = torch.tensor([sm_reads], dtype=torch.int64, device="cuda")
+        tm = torch.tensor([sm_t], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            smem = {"metric": "smem_seeding_mreads_per_s", "value": int(v[0]) / float(tm[0]) / 1e6, "unit": "Mreads/s", "steps": args.smem_steps,
+                    "ms_per_step": float(tm[0]) / args.smem_steps * 1e3, "dtype": "u64",
+                    "config": {"workload": "BASELINE.json configs[4]: 2^20 reads x 150 bp per GPU against a 64 MB FM-index slab "
+                                           "(67108864-bp random genome + reverse complement), three-pass SMEM seeding"}}
+            smem.update(sm_extras)
+
     line = None
     if rank == 0:
         # dominant kernel: the fp32 sweep; HIP events on the launch stream (accg_phmm_batch_time2)
@@ -276,7 +355,7 @@ def main():
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name},
             "roofline": roof, "cpu_baseline": cpu,
             "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
-            "sw": sw,
+            "sw": sw, "smem": smem,
         }
     batch.close()
     ctx.close()

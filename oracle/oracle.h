@@ -75,6 +75,7 @@ void orc_sw_score_many(const char* refs, int ref_stride, const int* refLens, con
 /* ---- SMEM seeding (PARITY UNPINNED, see smem_oracle.c) ------------------------------------------------------- */
 void orc_smem_batch(const uint32_t* bwt, const uint64_t* para, const uint8_t* seq, int seq_stride, const uint8_t* seq_len,
                     int batch, int max_out, uint64_t* out, int* mem_num, int n_threads);
+uint64_t orc_smem_last_lookups(void);   /* 64-byte index blocks requested by the last orc_smem_batch */
 void orc_smem_occ4(const uint32_t* bwt, const uint64_t* para, uint64_t k, uint64_t cnt[4]);
 
 #ifdef __cplusplus

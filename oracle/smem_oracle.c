@@ -26,9 +26,11 @@ static void push(ivec* v, const intv* e) {
 }
 
 /* Occ of the four symbols in B[0..k] (bwt_occ4, baseline.cpp:17-38); k == -1 -> zeros. */
+static _Thread_local uint64_t t_lookups;   /* 64-byte index blocks requested (the reference's DRAM_trans_size accounting, coarser) */
 static void occ4(const fmidx* f, uint64_t k, uint64_t cnt[4]) {
   if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
   k -= (k >= f->primary);                                   /* the sentinel is not stored */
+  t_lookups++;
   const uint32_t* blk = f->bwt + ((k >> 7) << 4);
   memcpy(cnt, blk, 32);
   const uint32_t* w = blk + 8;
@@ -160,14 +162,19 @@ static void collect(const fmidx* f, int len, const uint8_t* seq, ivec* mem, ivec
 
 /* smem_baseline (baseline.cpp:425-463): seq is batch x seq_stride codes (0-3, >= 4 ambiguous), out is batch x max_out
  * intervals of 4 uint64 {x0, x1, x2, info}; mem_num[i] is the uncapped count. */
+static uint64_t g_lookups;
+uint64_t orc_smem_last_lookups(void) { return g_lookups; }
+
 void orc_smem_batch(const uint32_t* bwt, const uint64_t* para, const uint8_t* seq, int seq_stride, const uint8_t* seq_len,
                     int batch, int max_out, uint64_t* out, int* mem_num, int n_threads) {
+  uint64_t total = 0;
   fmidx f; f.bwt = bwt; f.primary = para[0];
   for (int c = 0; c < 5; c++) f.L2[c] = para[1 + c];
   if (n_threads < 1) n_threads = 1;
-#pragma omp parallel num_threads(n_threads)
+#pragma omp parallel num_threads(n_threads) reduction(+ : total)
   {
     ivec mem = {0, 0, 0}, curr = {0, 0, 0}, back = {0, 0, 0};
+    t_lookups = 0;
 #pragma omp for schedule(dynamic, 64)
     for (int i = 0; i < batch; i++) {
       collect(&f, seq_len[i], seq + (size_t)i * seq_stride, &mem, &curr, &back);
@@ -176,7 +183,9 @@ void orc_smem_batch(const uint32_t* bwt, const uint64_t* para, const uint8_t* se
       memcpy(out + (size_t)i * max_out * 4, mem.a, sizeof(intv) * (size_t)keep);
     }
     free(mem.a); free(curr.a); free(back.a);
+    total += t_lookups;
   }
+  g_lookups = total;
 }
 
 /* Occ and one extension step exposed for the brute-force tests */

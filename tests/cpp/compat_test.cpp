@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -130,8 +131,58 @@ static int test_sw() {
   return bad;
 }
 
+// smem/main.cpp:217-373 flow: ocl_init once, smem_ocl per batch, compared with the CPU code (here the oracle); the
+// reference sorts both sides first (:176-177), which is unnecessary here because the order is reproduced as well.
+static int test_smem() {
+  int bad = 0;
+  const int G = 6000, n = 2 * G, nblk = (n + 127) / 128;
+  std::vector<uint8_t> text(n);
+  for (int i = 0; i < G; i++) text[i] = (uint8_t)(rng() % 4);
+  for (int i = 0; i < G; i++) text[G + i] = (uint8_t)(3 - text[G - 1 - i]);
+  // suffix array of text$ by plain sorting (toy size), BWT without the sentinel, BWA block layout
+  std::vector<int> sa(n + 1);
+  for (int i = 0; i <= n; i++) sa[i] = i;
+  std::sort(sa.begin(), sa.end(), [&](int a, int b) {
+    while (a < n && b < n) { if (text[a] != text[b]) return text[a] < text[b]; a++; b++; }
+    return a > b;     // the shorter suffix (sentinel first) sorts first
+  });
+  std::vector<uint8_t> bw; uint64_t primary = 0;
+  for (int i = 0; i <= n; i++) { if (sa[i] == 0) { primary = (uint64_t)i; continue; } bw.push_back(text[sa[i] - 1]); }
+  std::vector<uint32_t> bwt((size_t)nblk * 16, 0);
+  uint64_t run[4] = {0, 0, 0, 0};
+  for (int blk = 0; blk < nblk; blk++) {
+    memcpy(&bwt[(size_t)blk * 16], run, 32);
+    for (int s = 0; s < 128 && blk * 128 + s < n; s++) { uint8_t c = bw[blk * 128 + s]; run[c]++; bwt[(size_t)blk * 16 + 8 + (s >> 4)] |= (uint32_t)c << ((~s & 15) << 1); }
+  }
+  uint64_t para[7] = {primary, 0, 0, 0, 0, 0, (uint64_t)nblk};
+  for (int i = 0; i < n; i++) para[2 + text[i]]++;
+  for (int c = 1; c <= 4; c++) para[1 + c] += para[c];
+  const int B = 64;
+  std::vector<uint8_t> seq((size_t)B * SEQ_LENGTH, 0), len(B);
+  for (int r = 0; r < B; r++) {
+    int ln = 40 + (int)(rng() % 200), off = (int)(rng() % (G - ln));
+    len[r] = (uint8_t)ln;
+    for (int k = 0; k < ln; k++) seq[(size_t)r * SEQ_LENGTH + k] = (rng() % 50 == 0) ? (uint8_t)(rng() % 5) : text[off + k];
+  }
+  std::vector<bwtintv_t> got((size_t)B * MAX_INTV_ALLOC), want((size_t)B * MAX_INTV_ALLOC);
+  std::vector<int> gn(B), wn(B);
+  double kt[BANK_NUM];
+  ocl_init((char*)"unused", bwt.data(), para, (uint64_t)bwt.size(), got.data(), B);
+  smem_ocl((char*)"unused", bwt.data(), para, seq.data(), len.data(), B, got.data(), gn.data(), kt);
+  orc_smem_batch(bwt.data(), para, seq.data(), SEQ_LENGTH, len.data(), B, MAX_INTV_ALLOC, (uint64_t*)want.data(), wn.data(), 2);
+  int total = 0;
+  for (int r = 0; r < B; r++) {
+    if (gn[r] != wn[r]) { bad++; continue; }
+    total += gn[r];
+    if (memcmp(&got[(size_t)r * MAX_INTV_ALLOC], &want[(size_t)r * MAX_INTV_ALLOC], sizeof(bwtintv_t) * (size_t)gn[r])) bad++;
+  }
+  if (total < B) bad++;
+  printf("smem: %s (%d intervals, kernel %.0f ns)\n", bad ? "FAILED" : "ok", total, kt[0]);
+  return bad;
+}
+
 int main() {
-  int bad = test_pairhmm() + test_sw();
+  int bad = test_pairhmm() + test_sw() + test_smem();
   cleanup();
   return bad ? 1 : 0;
 }

@@ -59,6 +59,7 @@ def oracle():
         L.orc_sw_pair.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int] * 7 + [i32p, i32p, i32p, C.c_int, i32p, i32p, i32p]
         L.orc_sw_score_many.argtypes = [C.c_char_p, C.c_int, i32p, C.c_char_p, C.c_int, i32p] + [C.c_int] * 6 + [i32p, i32p, i32p, C.c_int]
         L.orc_smem_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_smem_last_lookups.restype = C.c_uint64
         L.orc_smem_occ4.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _oracle = L
     return _oracle

@@ -19,4 +19,4 @@ def test_reference_shaped_entry_points():
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "pairhmm: ok" in r.stdout and "htc-sw: ok" in r.stdout
+    assert "pairhmm: ok" in r.stdout and "htc-sw: ok" in r.stdout and "smem: ok" in r.stdout
