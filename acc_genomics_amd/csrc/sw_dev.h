@@ -41,6 +41,7 @@ int sw_pick_k(int lane_seq_len, int lpp);
 hipError_t sw_trace_launch(int K, int lpp, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t work_base, uint32_t n_work,
                            uint32_t bt_first, int sweep_cap, hipStream_t s);
 size_t sw_lds_bytes(int sweep_cap);
+__host__ __device__ inline int sw_group_stride(int sweep_cap) { return ((sweep_cap + 1 + 15) / 32) * 32 + 16; }   // >= cap + 1, = 16 mod 32
 inline uint64_t sw_bt_item_uint4(int sweep_cap, int lpp) { return (uint64_t)64 * (sweep_cap + lpp); }
 
 }  // namespace accg

@@ -15,7 +15,7 @@
 // sequence") is streamed from LDS one position per step, skewed one position per lane, so the only
 // cross-lane traffic is a DPP row_shr:1 of two values per step (H and the lane-direction gap of the
 // lane's last position).  Positions in front of the sequence are border clones that reproduce
-// H[.][0] out of the same recurrence (score 0 / -inf, open = -inf), so there is no border special
+// H[.][0] out of the same recurrence (score 0, or -inf with a -inf hand-off from the left under the prefill strategies), so there is no border special
 // case in the loop.  In 16-bit mode two pairs share a row in the lo/hi halves of every register
 // (v_pk_add_i16 clamp / v_pk_max_i16), so a wavefront works on 8 pairs.  Lanes are switched off
 // (EXEC) before their first and after their last sweep position, which freezes exactly the values
@@ -76,6 +76,12 @@ template <> struct Val<false> {
 
 // lane l <- lane l-1 inside a group of LPP lanes; the first lane of every group receives OLD.
 // 16 lanes = one DPP row (row_shr:1); 32/64 lanes: wave_shr:1 plus one select for lane 32.
+template <int LPP>
+__device__ __forceinline__ int group_shr1_var(int old, int v, bool leader) {   // same with a run-time value for the first lane
+  if (LPP == 16) return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false);
+  const int r = __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false);
+  return (LPP == 32 && leader) ? old : r;
+}
 template <int OLD, int LPP>
 __device__ __forceinline__ int group_shr1_old(int v, bool leader) {
   if (LPP == 16) return __builtin_amdgcn_update_dpp(OLD, v, 0x111, 0xF, 0xF, false);
@@ -116,8 +122,10 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   typedef typename VT::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // per group: sweep characters (two pairs packed lo|hi<<16) and the log of the last lane position
-  uint32_t* sweep_ch = reinterpret_cast<uint32_t*>(smem);                 // [4][sweep_cap + 1] (NG <= 4 used)
-  int32_t* edge_log = reinterpret_cast<int32_t*>(smem) + 4 * (sweep_cap + 1);   // [4][sweep_cap + 1] (bits of T)
+  // group stride = 16 mod 32 words: the two groups of a 32-lane half then read disjoint banks (ds_read_b32 has 32 banks)
+  const int gs = sw_group_stride(sweep_cap);
+  uint32_t* sweep_ch = reinterpret_cast<uint32_t*>(smem);                 // [4][gs] (NG <= 4 used)
+  int32_t* edge_log = reinterpret_cast<int32_t*>(smem) + 4 * gs;          // [4][gs] (bits of T)
 
   constexpr int NG = 64 / LPP;                 // pair groups per wavefront
   const int lane = threadIdx.x, g = lane / LPP, l = lane % LPP;
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
     }
 
   // ---- sweep characters into LDS -----------------------------------------------------------------
-  uint32_t* my_ch = sweep_ch + g * (sweep_cap + 1);
-  int32_t* my_log = edge_log + g * (sweep_cap + 1);
+  uint32_t* my_ch = sweep_ch + g * gs;
+  int32_t* my_log = edge_log + g * gs;
   for (int i = l; i < ns; i += LPP) {
     uint32_t c0 = have[0] ? sseq[0][i] : 0u, c1 = have[1] ? sseq[1][i] : 0u;
     my_ch[i + 1] = c0 | (c1 << 16);
@@ -153,29 +161,35 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   // ---- per-position constants ---------------------------------------------------------------------
   // position p (1-based along the lane sequence) of half h sits at flat index p - 1 + pad_h; flat < pad_h
   // is a border clone: score 0 (no prefill) or -inf (prefill), lane-direction open = -inf.
-  T ch[K], wm[K], wd[K], opn[K], Hp[K], G[K];
+  T ch[K], wm[K], wd[K], Hp[K], Ho[K], G[K];   // Ho = H + w_open of the previous sweep index (shared by both gap recurrences)
   const int W_M = a.w_match, W_X = a.w_mismatch, W_O = a.w_open, W_E = a.w_extend;
   const int NEG = VT::NEG;
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    int c_[2], wm_[2], wd_[2], op_[2], h_[2];
+    int c_[2], wm_[2], wd_[2], h_[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int pad = LPP * K - nl[h];
       const int p = l * K + k - pad + 1;       // 1-based position, <= 0: border clone
       if (have[h] && p >= 1) {
-        c_[h] = lseq[h][p - 1]; wm_[h] = W_M; wd_[h] = W_X - W_M; op_[h] = W_O;
+        c_[h] = lseq[h][p - 1]; wm_[h] = W_M; wd_[h] = W_X - W_M;
         h_[h] = prefill[h] ? W_O + (p - 1) * W_E : 0;                 // H at sweep index 0
       } else {
         c_[h] = 0x100;                                                 // never equals a base byte
-        wm_[h] = prefill[h] ? NEG / 2 : 0; wd_[h] = 0; op_[h] = NEG; h_[h] = 0;
+        wm_[h] = prefill[h] ? NEG / 2 : 0; wd_[h] = 0; h_[h] = 0;
       }
     }
     ch[k] = VT::make(c_[0], c_[1]); wm[k] = VT::make(wm_[0], wm_[1]); wd[k] = VT::make(wd_[0], wd_[1]);
-    opn[k] = VT::make(op_[0], op_[1]); Hp[k] = VT::make(h_[0], h_[1]); G[k] = VT::splat(NEG);
+    Hp[k] = VT::make(h_[0], h_[1]); G[k] = VT::splat(NEG);
   }
   const T ext = VT::splat(W_E), opn_s = VT::splat(W_O);
-  T h_in = VT::splat(0), d_in = VT::splat(0), f_in = VT::splat(NEG);
+#pragma unroll
+  for (int k = 0; k < K; k++) Ho[k] = VT::adds(Hp[k], opn_s);
+  // What the first lane of a group receives from "the left": H = 0 (its k = 0 is always a border clone whose own H is
+  // produced by score 0 / the sweep-direction gap), except under a prefill strategy, where -inf keeps the clone's
+  // lane-direction gap at -inf so that the clone reproduces H[i][0] = open + (i-1)*extend exactly.
+  const T h_left = VT::make(prefill[0] ? NEG : 0, prefill[1] ? NEG : 0);
+  T h_in = h_left, d_in = h_left, f_in = VT::splat(NEG);
   T h_last = Hp[K - 1], f_last = VT::splat(NEG);
   // what the border clone in front of lane 0 hands over: H[i][0] along the sweep
   // (lane 0, k = 0 is always a clone, so only its *inputs* matter: 0 / NEG below)
@@ -189,20 +203,21 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   for (int t = 1; t <= t_end; t++) {
     // hand-off from the lane on the left (all lanes, also the switched-off ones: their registers are frozen)
     d_in = h_in;
-    h_in = VT::from_bits(group_shr1_old<0, LPP>(VT::bits(h_last), l == 0));
+    h_in = VT::from_bits(group_shr1_var<LPP>(VT::bits(h_left), VT::bits(h_last), l == 0));
     f_in = VT::from_bits(P16 ? group_shr1_old<(int)0x80008000, LPP>(VT::bits(f_last), l == 0)
                              : group_shr1_old<NEG32, LPP>(VT::bits(f_last), l == 0));
     const int i = t - l;                       // this lane's sweep index
     if (i >= 1 && i <= ns) {
       const T c = VT::from_bits((int)my_ch[i]);
       T hup = h_in, hdiag = d_in, f = f_in;
+      T fo = VT::adds(h_in, opn_s);                                      // H of the position above + w_open
       unsigned pf = 0, pg = 0, pn = 0, pd = 0;
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const T hold = Hp[k];
-        const T fe = VT::adds(f, ext), fo = VT::adds(hup, opn[k]);
+        const T fe = VT::adds(f, ext);
         f = VT::mx(fe, fo);                                              // gap along the lanes
-        const T ge = VT::adds(G[k], ext), go = VT::adds(hold, opn_s);
+        const T ge = VT::adds(G[k], ext), go = Ho[k];
         G[k] = VT::mx(ge, go);                                           // gap along the sweep
         const T dg = VT::adds(hdiag, VT::score(ch[k], c, wm[k], wd[k]));
         const T m = VT::mx(G[k], f);
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
           pd = (pd << 1) | (LANE_IS_ALT ? VT::lt(f, G[k]) : VT::lt(G[k], f));   // right < down
         }
         hdiag = hold; hup = hn; Hp[k] = hn;
+        fo = VT::adds(hn, opn_s); Ho[k] = fo;
       }
       h_last = hup; f_last = f;
       if (BT) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + LPP) + t) * LPP + l] =
@@ -390,7 +406,7 @@ hipError_t launch_sel(int K, bool pack16, bool lane_is_alt, bool with_bt, const 
 
 }  // namespace
 
-size_t sw_lds_bytes(int sweep_cap) { return (size_t)8 * (sweep_cap + 1) * 4; }
+size_t sw_lds_bytes(int sweep_cap) { return (size_t)8 * sw_group_stride(sweep_cap) * 4; }
 
 hipError_t sw_launch(int K, int lpp, bool pack16, bool lane_is_alt, bool with_bt, const SwArgs& a, uint32_t wb, uint32_t n,
                      uint32_t bt_first, int cap, hipStream_t s) {
