@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   T dn[K];                    // dist of step t   (loaded one step ahead)
   load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
   unsigned o1 = hs[1];        // base index of step t+1 (loaded two steps ahead)
-  constexpr int U = 4;
+  constexpr int U = 8;
   while (t < t_end) {
     if (rm == 0 && nb - t >= U) {          // no lane is on a bubble for the next U steps
 #pragma unroll
