@@ -122,6 +122,10 @@ struct DevBuf {
     return ACCG_OK;
   }
   void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+  ~DevBuf() { release(); }      // error paths of batch_create free what was allocated so far
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
 };
 
 bool valid_base_lut(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N'; }
@@ -547,7 +551,8 @@ extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, doubl
     if (nresc) { r64.resize(b->pairs); ACCG_HIP(hipMemcpy(r64.data(), b->d_out64.p, b->pairs * sizeof(double), hipMemcpyDeviceToHost)); }
     const HostTables& t = host_tables();
     // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
-    for (uint64_t i = 0; i < b->pairs; i++) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)b->pairs; i++) {
       if (raw[i] < PHMM_MIN_ACCEPTED) out_log10[i] = log10(r64[i]) - t.log10_init_d;
       else out_log10[i] = (double)(log10f(raw[i]) - t.log10_init_f);
     }

@@ -12,6 +12,7 @@ struct accg_smem_index {
   accg_ctx* ctx = nullptr;
   uint32_t* d_bwt = nullptr;
   uint64_t words = 0, primary = 0, L2[5] = {0};
+  ~accg_smem_index() { if (d_bwt) hipFree(d_bwt); }
 };
 
 struct accg_smem_batch {
@@ -21,6 +22,7 @@ struct accg_smem_batch {
   SmemIntv *d_out = nullptr, *d_scratch = nullptr;
   int32_t* d_num = nullptr;
   uint64_t bases = 0;
+  ~accg_smem_batch() { for (void* p : {(void*)d_seq, (void*)d_len, (void*)d_out, (void*)d_num, (void*)d_scratch}) if (p) hipFree(p); }
 };
 
 extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para,
@@ -40,7 +42,6 @@ extern "C" void accg_smem_index_destroy(accg_smem_index* x) {
   if (!x) return;
   hipSetDevice(x->ctx->device);
   hipStreamSynchronize(x->ctx->stream);
-  if (x->d_bwt) hipFree(x->d_bwt);
   delete x;
 }
 
@@ -110,6 +111,5 @@ extern "C" void accg_smem_batch_destroy(accg_smem_batch* b) {
   if (!b) return;
   hipSetDevice(b->idx->ctx->device);
   hipStreamSynchronize(b->idx->ctx->stream);
-  for (void* p : {(void*)b->d_seq, (void*)b->d_len, (void*)b->d_out, (void*)b->d_num, (void*)b->d_scratch}) if (p) hipFree(p);
   delete b;
 }

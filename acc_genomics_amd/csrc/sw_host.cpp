@@ -34,6 +34,11 @@ struct accg_sw_batch {
   uint4* d_bt = nullptr; uint64_t bt_bytes = 0;
   int32_t *d_cig_n = nullptr, *d_cig_off = nullptr, *d_cig_el = nullptr;
   int max_el = 0;
+  ~accg_sw_batch() {            // also reached on the error paths of accg_sw_batch_create
+    for (void* p : {(void*)d_refs, (void*)d_alts, (void*)d_strat, (void*)d_rl, (void*)d_al, (void*)d_score, (void*)d_p1, (void*)d_p2,
+                    (void*)d_work, (void*)d_bt, (void*)d_cig_n, (void*)d_cig_off, (void*)d_cig_el})
+      if (p) hipFree(p);
+  }
 };
 
 extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, size_t ref_stride, const int32_t* ref_lens,
@@ -229,9 +234,5 @@ extern "C" void accg_sw_batch_destroy(accg_sw_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
-  for (void* p : {(void*)b->d_refs, (void*)b->d_alts, (void*)b->d_strat, (void*)b->d_rl, (void*)b->d_al, (void*)b->d_score,
-                  (void*)b->d_p1, (void*)b->d_p2, (void*)b->d_work, (void*)b->d_bt, (void*)b->d_cig_n, (void*)b->d_cig_off,
-                  (void*)b->d_cig_el})
-    if (p) hipFree(p);
   delete b;
 }

@@ -257,8 +257,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("NCCL_DEBUG", "WARN")     # keeps RCCL's version banner off stdout: rank 0 prints ONE JSON line
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ACCG_BENCH_FORCE_DIST"):     # the second form rehearses the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
