@@ -1,7 +1,10 @@
 // See accg_compat.h.  Everything here is host glue over include/accg.h; no arithmetic of the hot path
 // happens on the CPU.
 #include "accg_compat.h"
+#include <stdio.h>
 #include <string.h>
+#include <fstream>
+#include <sstream>
 #include <stdexcept>
 #include "../../../include/accg.h"
 
@@ -66,6 +69,65 @@ int deserialize(const void* buf, hap_t*& haps) {
 }
 int deserialize(const std::string& data, read_t*& reads) { return deserialize((const void*)data.data(), reads); }
 int deserialize(const std::string& data, hap_t*& haps) { return deserialize((const void*)data.data(), haps); }
+
+// ---- host_tb text files (pairhmm/host/main.cpp:67-159) -------------------------------------------------------
+namespace {
+std::vector<std::string> tokens_of_next_line(std::ifstream& in) {
+  std::string line;
+  std::getline(in, line);
+  std::istringstream ss(line);
+  std::vector<std::string> t;
+  for (std::string w; ss >> w;) t.push_back(w);
+  return t;
+}
+}  // namespace
+void get_input(int& num_read, int& num_hap, read_t*& reads, hap_t*& haps, const char* filename) {
+  std::ifstream in(filename);
+  if (!in.good()) throw std::runtime_error(std::string("get_input: cannot open ") + filename);
+  auto head = tokens_of_next_line(in);
+  if (head.size() != 4) throw std::runtime_error("get_input: bad header");
+  num_read = std::stoi(head[1]); num_hap = std::stoi(head[3]);
+  reads = (read_t*)malloc(sizeof(read_t) * (size_t)(num_read > 0 ? num_read : 1));
+  haps = (hap_t*)malloc(sizeof(hap_t) * (size_t)(num_hap > 0 ? num_hap : 1));
+  std::string skip;
+  for (int i = 0; i < num_read; i++) {
+    auto t = tokens_of_next_line(in);
+    if (t.size() != 1) throw std::runtime_error("get_input: bad read length line");
+    const int len = std::stoi(t[0]);
+    read_t& r = reads[i];
+    r.len = len;
+    char** field[5] = {&r._b, &r._q, &r._i, &r._d, &r._c};
+    for (int f = 0; f < 5; f++) {
+      *field[f] = (char*)malloc((size_t)len + 1);
+      std::getline(in, skip);                       // label line
+      auto v = tokens_of_next_line(in);
+      if ((int)v.size() != len) throw std::runtime_error("get_input: field length mismatch");
+      for (int k = 0; k < len; k++) (*field[f])[k] = (char)std::stoi(v[k]);
+      (*field[f])[len] = '\0';
+    }
+  }
+  std::getline(in, skip);                           // empty line
+  for (int j = 0; j < num_hap; j++) {
+    auto t = tokens_of_next_line(in);
+    if (t.size() != 1) throw std::runtime_error("get_input: bad hap length line");
+    haps[j].len = std::stoi(t[0]);
+    std::getline(in, skip);                         // label line
+    std::string bases;
+    std::getline(in, bases);
+    if ((int)bases.size() != haps[j].len) throw std::runtime_error("get_input: hap length mismatch");
+    haps[j]._b = strdup(bases.c_str());
+  }
+}
+int get_output(double* likelihood, int size, const char* filename) {
+  std::ifstream in(filename);
+  if (!in.good()) { printf("bad file name %s\n", filename); return 1; }
+  for (int i = 0; i < size; i++) {
+    double shown; long long bits;
+    in >> shown >> bits;
+    memcpy(&likelihood[i], &bits, 8);               // the bit pattern is authoritative (main.cpp:150-156)
+  }
+  return 0;
+}
 
 // ---- one lazily created context per process (the reference keeps a global OpenCLEnv, PairHMMFpga.cpp:8) ----
 namespace {

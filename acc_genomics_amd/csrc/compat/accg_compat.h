@@ -29,6 +29,13 @@ std::string serialize(const hap_t* haps, int num);
 int deserialize(const std::string& data, read_t*& reads);
 int deserialize(const std::string& data, hap_t*& haps);
 
+// host_tb text format (pairhmm/host/main.cpp:67-159): `input<i>` = header "<label> numRead <label> numHap", per read a
+// length line followed by five (label line, integer line) pairs for _b (ASCII codes), _q, _i, _d, _c, an empty line,
+// per hap a length line, a label line and the literal bases; `output<i>` = per pair "<decimal> <int64 bit pattern>".
+// Arrays are malloc'ed as the reference does (free_reads / free_haps; get_input's hap bases come from strdup).
+void get_input(int& num_read, int& num_hap, read_t*& reads, hap_t*& haps, const char* filename);
+int get_output(double* likelihood, int size, const char* filename);
+
 #define MAX_READ_LEN 192      /* pairhmm/xlnx/common/common.h:3-6: limits of the FPGA bundle, kept for callers */
 #define MAX_HAP_LEN 1024
 #define MAX_RSDATA_NUM 2048
