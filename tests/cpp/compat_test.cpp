@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include "../../acc_genomics_amd/csrc/compat/accg_compat.h"
+#include "../../acc_genomics_amd/csrc/compat/accg_task.h"
+#include <dlfcn.h>
 #include "../../oracle/oracle.h"
 
 static std::mt19937_64 rng(0xACC6E0);
@@ -51,6 +53,18 @@ static int test_pairhmm() {
     uint64_t cells = 0; for (int i = 0; i < nr; i++) for (int j = 0; j < nh; j++) cells += (uint64_t)rt[i].len * ht[j].len;
     float* raw = compute_fpga("unused.xclbin", rs, hs, cells);
     if (!raw) { printf("compute_fpga skipped\n"); return 1; }
+    {   // the task plugin, loaded the way an accelerator manager loads it: dlopen + create()/destroy()
+      void* so = dlopen("libaccg_compat.so", RTLD_NOW);
+      auto mk = so ? (task_host::Task * (*)()) dlsym(so, "create") : nullptr;
+      auto rm = so ? (void (*)(task_host::Task*))dlsym(so, "destroy") : nullptr;
+      if (!mk || !rm) { printf("dlopen/create failed: %s\n", dlerror()); return 1; }
+      task_host::Task* t = mk();
+      t->setInput(0, &cells, 8); t->setInput(1, rs.data(), rs.size()); t->setInput(2, hs.data(), hs.size());
+      t->prepare(); t->compute();
+      const std::vector<float>& ob = t->getOutputBlock(0);
+      if (ob.size() != (size_t)nr * nh || memcmp(ob.data(), raw, sizeof(float) * ob.size())) { printf("task plugin output differs from compute_fpga\n"); bad++; }
+      rm(t);
+    }
     for (int i = 0; i < nr; i++)
       for (int j = 0; j < nh; j++) {
         const Read& r = in.reads[i]; const std::string& h = in.haps[j].bases;

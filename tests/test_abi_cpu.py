@@ -68,5 +68,5 @@ def test_compat_library_exports_reference_names():
     syms = os.popen("nm -DC %s" % p).read()
     for name in ("compute_fpga(", "FalconPairHMM::computePairhmm(", "FalconSWFPGA_run(", "FalconSWFPGA_init(", "_smithWatermanRun(",
                  "SWPairwiseAlignmentMultiBatch(", "serialize(void*, read_t const*, int)", "deserialize(void const*, hap_t*&)",
-                 "free_reads(", "cleanup()", "ocl_init(", "smem_ocl("):
+                 "free_reads(", "cleanup()", "ocl_init(", "smem_ocl(", "PairHMM::prepare()", "PairHMM::compute()", " create", " destroy"):
         assert name in syms, name
