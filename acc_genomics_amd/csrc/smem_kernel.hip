@@ -11,12 +11,16 @@
 // interval lists (curr / back of bwt_smem1a_new, up to 255 entries each) live in a thread-interleaved HBM scratch so
 // that the lanes of a wave touch neighbouring 32-byte elements.  Occ is computed with popcounts over the 2-bit
 // words instead of the reference's byte table; the counts are identical by definition.
+#include <stdlib.h>
 #include "smem_dev.h"
 
 namespace accg {
 namespace {
 
 constexpr int MIN_SEED_LEN = 19;   // smem/common/common.h:37
+#ifndef SMEM_MIN_WAVES
+#define SMEM_MIN_WAVES 1
+#endif
 
 struct Ctx {
   const uint32_t* bwt;
@@ -185,7 +189,7 @@ __device__ int seed_strategy1(const Ctx& f, int len, const uint8_t* q, int x, in
   return len;
 }
 
-__global__ __launch_bounds__(64) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+__global__ __launch_bounds__(64, SMEM_MIN_WAVES) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;
@@ -212,11 +216,174 @@ __global__ __launch_bounds__(64) void smem_kernel(SmemArgs a, uint32_t read_base
   a.mem_num[rd] = mem.n;
 }
 
+// ---- lock-step variant -------------------------------------------------------------------------------------
+// The direct transcription above lets the 64 reads of a wavefront drift into different loops, so that the expensive
+// part - bwt_extend: two 64-byte block reads + ~150 VALU ops - runs with ~22 % of the lanes on average
+// (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU, profiles/).  Here every read is an explicit state machine: each round all
+// lanes advance their own control flow up to their next bwt_extend request, then the whole wavefront executes ONE
+// bwt_extend together.  Same functions, same order of results.
+enum : int {
+  P1_NEXT, A_INIT, A_FWD, A_FWD_RES, A_BACK_INIT, A_ITER, A_BK_LOOP, A_BK_RES, A_BK_DONE, A_FE_K, A_FE_M, A_FE_RES, A_POST,
+  A_RETURN, P2_NEXT, P3_NEXT, P3_LOOP, P3_RES, DONE
+};
+
+__global__ __launch_bounds__(64) void smem_kernel_fsm(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = tid < n_reads;
+  const uint32_t rd = read_base + (live ? tid : 0);
+  Ctx f; f.bwt = a.bwt; f.primary = a.primary;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = a.L2[c];
+  const uint8_t* q = a.seq + (size_t)rd * a.seq_stride;
+  const int len = live ? a.seq_len[rd] : 0;
+  Lists L; L.base = a.scratch + (live ? tid : 0); L.stride = a.n_threads;
+  Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = 0;
+
+  int st = live ? P1_NEXT : DONE, pass = 1;
+  int x = 0, i = 0, i2 = 0, kk = 0, m = 0, k2 = 0, old_n = 0, min_intv = 1, ret = 0;
+  int n_curr = 0, n_back = 0, start = 0, stop = 0, max_len = 0;
+  SmemIntv ik, temp, ci, ok[4];
+  ik.x0 = ik.x1 = ik.x2 = ik.info = 0; temp = ik; ci = ik;
+  bool req = false, req_back = false;
+
+  for (;;) {
+    // ---- every lane runs its own control flow up to its next bwt_extend (or to the end) ----
+    while (!req && st != DONE) {
+      switch (st) {
+        case P1_NEXT:                                         // mem_collect_intv_new, first pass (:394-400)
+          while (x < len && q[x] >= 4) x++;
+          if (x >= len) { old_n = mem.n < (int)mem.cap ? mem.n : (int)mem.cap; k2 = 0; pass = 2; st = P2_NEXT; }
+          else { min_intv = 1; st = A_INIT; }
+          break;
+        case P2_NEXT: {                                       // second pass (:403-408)
+          bool go = false;
+          while (k2 < old_n && !go) {
+            const SmemIntv p = mem.a[k2++];
+            const int s0 = (int)(p.info >> 32), e0 = (int)(int32_t)p.info;
+            if (e0 - s0 < 28 || p.x2 > 10) continue;
+            x = (s0 + e0) >> 1; min_intv = (int)p.x2 + 1; go = true;
+          }
+          if (go) st = (q[x] > 3) ? P2_NEXT : A_INIT;
+          else { x = 0; pass = 3; st = P3_NEXT; }
+        } break;
+        case A_INIT:                                          // bwt_smem1a_new prologue (:193-197)
+          if (min_intv < 1) min_intv = 1;
+          ik = set_intv1(f, q[x]); ik.info = (uint64_t)(x + 1);
+          n_curr = 0; n_back = 0; i = x + 1; temp.x0 = temp.x1 = temp.x2 = temp.info = 0;
+          st = A_FWD;
+          break;
+        case A_FWD:                                           // forward extension (:199-216)
+          if (i >= len) { L.curr(n_curr++) = ik; st = A_BACK_INIT; }
+          else if (q[i] < 4) { req = true; req_back = false; st = A_FWD_RES; }
+          else { L.curr(n_curr++) = ik; st = A_BACK_INIT; }
+          break;
+        case A_FWD_RES: {
+          const SmemIntv nx = pick(ok, 3 - q[i]);
+          bool stop_now = false;
+          if (nx.x2 != ik.x2) { L.curr(n_curr++) = ik; stop_now = nx.x2 < (uint64_t)min_intv; }
+          if (stop_now) st = A_BACK_INIT;
+          else { ik = nx; ik.info = (uint64_t)(i + 1); i++; st = A_FWD; }
+        } break;
+        case A_BACK_INIT:
+          ret = (int)L.curr(n_curr - 1).info;
+          start = x; stop = x; max_len = 0; i2 = 0;
+          st = A_ITER;
+          break;
+        case A_ITER:                                          // :220-299
+          if (i2 >= n_curr) { st = A_RETURN; break; }
+          ci = L.curr(i2);
+          ik = ci; ik.info |= (uint64_t)x << 32;
+          if (n_back == 0 || stop - start >= 3) { n_back = 0; L.back(n_back++) = ik; kk = x - 1; st = A_BK_LOOP; }
+          else { stop = (int)ci.info; kk = n_back - 1; st = A_FE_K; }
+          break;
+        case A_BK_LOOP:                                       // "backenlarge" (:224-241)
+          if (kk < 0 || q[kk] >= 4) st = A_BK_DONE;
+          else { req = true; req_back = true; st = A_BK_RES; }
+          break;
+        case A_BK_RES: {
+          const SmemIntv nx = pick(ok, q[kk]);
+          if (nx.x2 < (uint64_t)min_intv) st = A_BK_DONE;
+          else { ik = nx; ik.info = ci.info | (uint64_t)kk << 32; L.back(n_back++) = ik; kk--; st = A_BK_LOOP; }
+        } break;
+        case A_BK_DONE:
+          start = (int)ci.info;
+          stop = (i2 == n_curr - 1) ? len : (int)L.curr(i2 + 1).info;
+          if (i2 != 0 && (ik.info >> 32) > (temp.info >> 32) && (int)temp.info - (int)(temp.info >> 32) >= MIN_SEED_LEN) mem.push(temp);
+          temp = ik;
+          st = A_POST;
+          break;
+        case A_FE_K:                                          // "forwardenlarge" (:255-281)
+          if (kk < 0) { st = A_POST; break; }
+          ik = L.back(kk); m = start + 1;
+          st = A_FE_M;
+          break;
+        case A_FE_M:
+          if (m > stop) { kk--; st = A_FE_K; }               // empty inner loop: nothing reached
+          else { req = true; req_back = false; st = A_FE_RES; }
+          break;
+        case A_FE_RES: {
+          const SmemIntv nx = pick(ok, 3 - q[m - 1]);
+          if (nx.x2 < (uint64_t)min_intv) { kk--; st = A_FE_K; break; }
+          ik = nx;
+          if (m == stop) {
+            ik.info = ci.info | (uint64_t)(x - kk) << 32;
+            if ((uint64_t)(x - kk) > (temp.info >> 32) && (int)temp.info - (int)(temp.info >> 32) >= MIN_SEED_LEN) mem.push(temp);
+            temp = ik;
+            st = A_POST;
+          } else { m++; st = A_FE_M; }
+        } break;
+        case A_POST:                                          // :283-298
+          i2++;
+          if (i2 < n_curr) max_len = (int)(temp.info >> 32) + (int)L.curr(i2).info;
+          while (max_len < MIN_SEED_LEN && i2 < n_curr) {
+            i2++;
+            if (i2 < n_curr) stop = (int)L.curr(i2).info;
+            max_len = (int)(temp.info >> 32) + stop;
+          }
+          if (i2 >= n_curr && (int)temp.info - (int)(temp.info >> 32) >= MIN_SEED_LEN) mem.push(temp);
+          st = A_ITER;
+          break;
+        case A_RETURN:
+          if (pass == 1) { x = ret; st = P1_NEXT; } else st = P2_NEXT;
+          break;
+        case P3_NEXT:                                         // third pass (:411-419) + bwt_seed_strategy1 (:306-327)
+          while (x < len && q[x] >= 4) x++;
+          if (x >= len) st = DONE;
+          else { ik = set_intv1(f, q[x]); i = x + 1; st = P3_LOOP; }
+          break;
+        case P3_LOOP:
+          if (i >= len) { x = len; st = P3_NEXT; }
+          else if (q[i] >= 4) { x = i + 1; st = P3_NEXT; }
+          else { req = true; req_back = false; st = P3_RES; }
+          break;
+        case P3_RES: {
+          const SmemIntv nx = pick(ok, 3 - q[i]);
+          if (nx.x2 < 20 && i - x >= MIN_SEED_LEN) {
+            SmemIntv mm = nx; mm.info = (uint64_t)x << 32 | (uint64_t)(i + 1);
+            if (mm.x2 > 0) mem.push(mm);
+            x = i + 1; st = P3_NEXT;
+          } else { ik = nx; i++; st = P3_LOOP; }
+        } break;
+        default: st = DONE; break;
+      }
+    }
+    if (!__any(req)) break;                                   // every lane is DONE
+    // ---- one bwt_extend for the whole wavefront ----
+    if (req) { extend(f, ik, ok, req_back); req = false; }
+  }
+  if (live) a.mem_num[rd] = mem.n;
+}
+
 }  // namespace
 
 hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
-  hipLaunchKernelGGL(smem_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, read_base, n_reads);
+  // Measured on configs[4]: the lock-step variant is 35 % SLOWER (43.5 vs 32.1 ms per 2^20 reads) - serialising the cheap
+  // per-lane control flow costs more than the divergent bwt_extend it removes, and the loads of a wave bunch up.
+  // It stays selectable for A/B runs.
+  static const bool fsm = getenv("ACCG_SMEM_FSM") != nullptr;
+  if (fsm) hipLaunchKernelGGL(smem_kernel_fsm, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, read_base, n_reads);
+  else hipLaunchKernelGGL(smem_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, read_base, n_reads);
   return hipGetLastError();
 }
 
