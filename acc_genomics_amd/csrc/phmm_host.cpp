@@ -383,7 +383,7 @@ int launch_f32(accg_phmm_batch* b, int mode) {
   }
   return ACCG_OK;
 }
-int launch_rescue(accg_phmm_batch* b) {
+int launch_rescue(accg_phmm_batch* b, int mode) {
   hipStream_t s = b->ctx->stream;
   PhmmPlanArgs p;
   p.regions = b->d_regions.p; p.chunks = b->d_chunks.p; p.sorted_reads = b->d_sorted_reads.p; p.rd = b->d_rd.p;
@@ -398,7 +398,7 @@ int launch_rescue(accg_phmm_batch* b) {
     const uint32_t bound = std::min(b->rescue_bound[c], b->rescue_cap);
     if (!bound) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
-    ACCG_HIP(phmm_launch_rescue_f64(cls_k[c], cls_lpp[c], a, (uint32_t)c * b->rescue_cap, bound, s));
+    ACCG_HIP(phmm_launch_rescue_f64(cls_k[c], cls_lpp[c], mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, s));
   }
   return ACCG_OK;
 }
@@ -485,7 +485,7 @@ extern "C" int accg_phmm_batch_run(accg_phmm_batch* b, int mode) {
   ACCG_HIP(hipSetDevice(b->ctx->device));
   int st = launch_f32(b, mode);
   if (st != ACCG_OK) return st;
-  return launch_rescue(b);
+  return launch_rescue(b, mode);
 }
 
 // fp64 over every pair (FalconPairHMM::computePairhmmAVX with use_double = true, FalconPairHMM.cpp:82);
@@ -516,12 +516,12 @@ extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int
   int st;
   for (int i = 0; i < warmup; i++) {
     if ((st = launch_f32(b, mode)) != ACCG_OK) return st;
-    if (what == 0 && (st = launch_rescue(b)) != ACCG_OK) return st;
+    if (what == 0 && (st = launch_rescue(b, mode)) != ACCG_OK) return st;
   }
   ACCG_HIP(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < iters; i++) {
     if ((st = launch_f32(b, mode)) != ACCG_OK) return st;
-    if (what == 0 && (st = launch_rescue(b)) != ACCG_OK) return st;
+    if (what == 0 && (st = launch_rescue(b, mode)) != ACCG_OK) return st;
   }
   ACCG_HIP(hipEventRecord(c->ev1, c->stream));
   ACCG_HIP(hipEventSynchronize(c->ev1));
@@ -529,7 +529,7 @@ extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int
   ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *ms_per_run = ms / iters;
   b->last_kernel_ns = (uint64_t)((double)ms / iters * 1e6);
-  if (what != 0) { if ((st = launch_rescue(b)) != ACCG_OK) return st; }   // leave the buffers consistent
+  if (what != 0) { if ((st = launch_rescue(b, mode)) != ACCG_OK) return st; }   // leave the buffers consistent
   return ACCG_OK;
 }
 extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, float* ms_per_run) {

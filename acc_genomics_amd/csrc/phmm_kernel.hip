@@ -406,8 +406,8 @@ hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a
 hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
   return launch<double, true, false>(K, lpp, a, wb, n, s);
 }
-hipError_t phmm_launch_rescue_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, true>(K, lpp, a, wb, n, s);
+hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return strict ? launch<double, true, true>(K, lpp, a, wb, n, s) : launch<double, false, true>(K, lpp, a, wb, n, s);
 }
 
 // (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support

@@ -342,11 +342,11 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
       if (bit(p1, p2, 3)) {                     // down: deletion of kd rows
         ns_ = 2;
         int r = p1;
-        while (!bit(r, p2, P_VOPEN)) { step++; r--; }
+        while (r > 1 && !bit(r, p2, P_VOPEN)) { step++; r--; }   // row 1 always opens (its extension source is -inf); the bound is a guard
       } else {                                  // right: insertion of ki columns
         ns_ = 1;
         int c = p2;
-        while (!bit(p1, c, P_HOPEN)) { step++; c--; }
+        while (c > 1 && !bit(p1, c, P_HOPEN)) { step++; c--; }
       }
     }
     if (ns_ == 0) { p1--; p2--; } else if (ns_ == 1) p2 -= step; else p1 -= step;
