@@ -1,0 +1,156 @@
+// Host side of the BWA-MEM seed-extension path: the role of the FPGA host's task packing (bwa-sw/sdaccel: seed_param /
+// seed_seq streams into seed_proc, smithwaterman.cpp:564-584) and of reading back the five result words (:666-670).
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <numeric>
+#include <vector>
+#include "accg_internal.h"
+#include "bwasw_dev.h"
+
+using namespace accg;
+
+struct accg_bwasw_batch {
+  accg_ctx* ctx = nullptr;
+  uint32_t n = 0;
+  uint8_t* d_blob = nullptr;
+  BwaswSeed* d_seeds = nullptr;
+  BwaswWork* d_work = nullptr;
+  int16_t* d_out = nullptr;
+  std::vector<uint16_t> seed_index;                      // echoed into the packed result words
+  struct Launch { int K; uint32_t work_off, n_work; };
+  std::vector<Launch> launches;
+  uint64_t cells = 0;
+  ~accg_bwasw_batch() { for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) hipFree(p); }
+};
+
+extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const uint8_t* seqs, const uint32_t* seq_off,
+                                       const uint16_t* params, accg_bwasw_batch** out) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out || (n_seeds && (!seqs || !seq_off || !params))) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<accg_bwasw_batch> b(new accg_bwasw_batch);
+  b->ctx = ctx; b->n = n_seeds;
+  std::vector<BwaswSeed> seeds(n_seeds);
+  std::vector<int> kclass(n_seeds);
+  std::vector<uint32_t> rows(n_seeds);
+  b->seed_index.resize(n_seeds);
+  size_t blob_bytes = 0;
+  for (uint32_t i = 0; i < n_seeds; i++) {
+    const uint16_t* p = params + (size_t)i * 7;
+    // device limits: uint8_t qlen with a `j <= qlen` loop, uint11_t tlen, seq_mem[2048], ap_int<10> prev (smithwaterman.cpp:75-135, :520-556)
+    if (p[0] > ACCG_BWASW_MAX_QLEN || p[2] > ACCG_BWASW_MAX_QLEN) return ACCG_ERR_TOO_LONG;
+    if (p[1] > ACCG_BWASW_MAX_TLEN || p[3] > ACCG_BWASW_MAX_TLEN) return ACCG_ERR_TOO_LONG;
+    if ((uint32_t)p[0] + p[1] + p[2] + p[3] > 2048u) return ACCG_ERR_TOO_LONG;
+    if ((uint32_t)p[4] + p[0] + p[2] > 511u) return ACCG_ERR_TOO_LONG;
+    BwaswSeed& s = seeds[i];
+    s.qlen[0] = p[0]; s.tlen[0] = p[1]; s.qlen[1] = p[2]; s.tlen[1] = p[3]; s.seed_len = p[4]; s.seed_qbeg = p[5]; s.pad_ = 0;
+    b->seed_index[i] = p[6];
+    s.q_off[0] = (uint32_t)blob_bytes;               blob_bytes += p[0];
+    s.q_off[1] = (uint32_t)blob_bytes;               blob_bytes += p[2];
+    blob_bytes = (blob_bytes + 3) & ~(size_t)3;
+    s.t_off[0] = (uint32_t)blob_bytes;               blob_bytes += (p[1] + 3u) & ~3u;
+    s.t_off[1] = (uint32_t)blob_bytes;               blob_bytes += (p[3] + 3u) & ~3u;
+    if (blob_bytes > 0xFFFFFFF0ull) return ACCG_ERR_TOO_LONG;
+    const int ql = std::max<int>(p[0], p[2]);
+    kclass[i] = (ql + 1 + 15) / 16;
+    rows[i] = (uint32_t)p[1] + p[3];
+    b->cells += (uint64_t)p[0] * p[1] + (uint64_t)p[2] * p[3];
+  }
+  std::vector<uint8_t> blob(blob_bytes + 16, 4);
+  for (uint32_t i = 0; i < n_seeds; i++) {
+    const BwaswSeed& s = seeds[i];
+    const uint8_t* src = seqs + seq_off[i];           // [left query][right query][left target][right target]
+    const uint32_t len[4] = {s.qlen[0], s.qlen[1], s.tlen[0], s.tlen[1]};
+    const uint32_t dst[4] = {s.q_off[0], s.q_off[1], s.t_off[0], s.t_off[1]};
+    for (int part = 0; part < 4; part++) {
+      for (uint32_t k = 0; k < len[part]; k++) { const uint8_t c = src[k]; blob[dst[part] + k] = c > 3 ? 4 : c; }
+      src += len[part];
+    }
+  }
+  // four seeds per wavefront: same K, similar row counts (a wavefront runs as long as its longest seed)
+  std::vector<uint32_t> order(n_seeds);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    if (kclass[x] != kclass[y]) return kclass[x] > kclass[y];
+    if (rows[x] != rows[y]) return rows[x] > rows[y];
+    return x < y;
+  });
+  std::vector<BwaswWork> work;
+  for (uint32_t i = 0; i < n_seeds;) {
+    const int K = kclass[order[i]];
+    accg_bwasw_batch::Launch L{K, (uint32_t)work.size(), 0};
+    while (i < n_seeds && kclass[order[i]] == K) {
+      BwaswWork w;
+      for (int g = 0; g < 4; g++) w.seed[g] = (i < n_seeds && kclass[order[i]] == K) ? order[i++] : BWASW_EMPTY;
+      work.push_back(w);
+      L.n_work++;
+    }
+    b->launches.push_back(L);
+  }
+  ACCG_HIP(hipMalloc((void**)&b->d_blob, blob.size()));
+  ACCG_HIP(hipMalloc((void**)&b->d_seeds, std::max<size_t>(n_seeds, 1) * sizeof(BwaswSeed)));
+  ACCG_HIP(hipMalloc((void**)&b->d_work, std::max<size_t>(work.size(), 1) * sizeof(BwaswWork)));
+  ACCG_HIP(hipMalloc((void**)&b->d_out, std::max<size_t>(n_seeds, 1) * 8 * sizeof(int16_t)));
+  ACCG_HIP(hipMemcpy(b->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  if (n_seeds) {
+    ACCG_HIP(hipMemcpy(b->d_seeds, seeds.data(), n_seeds * sizeof(BwaswSeed), hipMemcpyHostToDevice));
+    ACCG_HIP(hipMemcpy(b->d_work, work.data(), work.size() * sizeof(BwaswWork), hipMemcpyHostToDevice));
+  }
+  *out = b.release();
+  return ACCG_OK;
+}
+extern "C" uint64_t accg_bwasw_batch_cells(const accg_bwasw_batch* b) { return b ? b->cells : 0; }
+
+extern "C" int accg_bwasw_batch_run(accg_bwasw_batch* b) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  BwaswArgs a;
+  a.blob = b->d_blob; a.seeds = b->d_seeds; a.out = b->d_out;
+  for (const auto& L : b->launches) {
+    a.work = b->d_work + L.work_off;
+    ACCG_HIP(bwasw_launch(L.K, a, L.n_work, b->ctx->stream));
+  }
+  return ACCG_OK;
+}
+extern "C" int accg_bwasw_batch_time(accg_bwasw_batch* b, int warmup, int iters, float* ms_per_run) {
+  if (!b || !ms_per_run || iters <= 0 || warmup < 0) return ACCG_ERR_BAD_ARG;
+  accg_ctx* c = b->ctx;
+  int st;
+  for (int i = 0; i < warmup; i++) if ((st = accg_bwasw_batch_run(b)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < iters; i++) if ((st = accg_bwasw_batch_run(b)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
+  ACCG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_run = ms / iters;
+  return ACCG_OK;
+}
+extern "C" int accg_bwasw_batch_results(accg_bwasw_batch* b, int16_t* fields, int32_t* words) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  if (!b->n) return ACCG_OK;
+  std::vector<int16_t> raw((size_t)b->n * 8);
+  ACCG_HIP(hipMemcpy(raw.data(), b->d_out, raw.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < b->n; i++) {
+    const int16_t* r = raw.data() + (size_t)i * 8;
+    if (fields) memcpy(fields + (size_t)i * 7, r, 7 * sizeof(int16_t));
+    if (words) {                                      // the match stream of smithwaterman.cpp:666-670
+      int32_t* w = words + (size_t)i * 5;
+      w[0] = b->seed_index[i];
+      w[1] = (int32_t)(((uint32_t)(uint16_t)r[0]) | ((uint32_t)(uint16_t)r[1] << 16));
+      w[2] = (int32_t)(((uint32_t)(uint16_t)r[2]) | ((uint32_t)(uint16_t)r[3] << 16));
+      w[3] = (int32_t)(((uint32_t)(uint16_t)r[4]) | ((uint32_t)(uint16_t)r[5] << 16));
+      w[4] = (int32_t)(uint16_t)r[6];
+    }
+  }
+  return ACCG_OK;
+}
+extern "C" void accg_bwasw_batch_destroy(accg_bwasw_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  delete b;
+}

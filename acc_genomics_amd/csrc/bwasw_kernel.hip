@@ -1,0 +1,228 @@
+// BWA-MEM seed extension (banded, adaptive trimming) on gfx950.  Behaviour restated from bwa-sw/sdaccel/smithwaterman.cpp:
+// sw_extend :75-273 (one side, up to two band tries) and seed_proc :586-670 (left side, then right side seeded with the left
+// score).  The FPGA walks one row cell by cell; here a row is one step of a 16-lane group:
+//
+//   * a seed owns 16 lanes, a wavefront four seeds; lane l keeps K consecutive entries of the eh[] row buffer (H of the row
+//     above shifted by one column, E) in registers, right-aligned so that entry `qlen` is the last entry of lane 15;
+//   * the insertion chain f[j+1] = max(f[j]-1, M[j]-7, 0) is a max-plus scan: each lane runs it locally from 0, the carry-in
+//     comes from an exclusive prefix max over the group (4 DPP row_shr steps), and the true f is max(local, carry - k);
+//   * the row's arg-max (last column on ties), the first/last non-zero entries that drive the adaptive band, and the value at
+//     the query end are group reductions (DPP butterflies), so the trimming state (beg, end) stays replicated per lane;
+//   * the substitution score is a 4-bit field of a per-column word selected by the row's target base.
+//
+// All arithmetic is int32; the FPGA's ap_int widths never wrap inside the limits the host enforces.
+#include "bwasw_dev.h"
+
+namespace accg {
+namespace {
+
+constexpr int NEGV = -(1 << 28);
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ int dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false); }
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
+
+// all-reduce max over the 16 lanes of a DPP row
+__device__ __forceinline__ int group_allmax(int v) {
+  v = imax(v, dpp<0xB1>(v, v));      // quad_perm [1,0,3,2]
+  v = imax(v, dpp<0x4E>(v, v));      // quad_perm [2,3,0,1]
+  v = imax(v, dpp<0x141>(v, v));     // row_half_mirror
+  v = imax(v, dpp<0x140>(v, v));     // row_mirror
+  return v;
+}
+__device__ __forceinline__ int pkmax(int a, int b) {
+  return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ int group_allmax_pk(int v) {
+  v = pkmax(v, dpp<0xB1>(v, v));
+  v = pkmax(v, dpp<0x4E>(v, v));
+  v = pkmax(v, dpp<0x141>(v, v));
+  v = pkmax(v, dpp<0x140>(v, v));
+  return v;
+}
+// exclusive prefix max over the row
+__device__ __forceinline__ int group_exscan_max(int v) {
+  v = imax(v, dpp<0x111>(NEGV, v));
+  v = imax(v, dpp<0x112>(NEGV, v));
+  v = imax(v, dpp<0x114>(NEGV, v));
+  v = imax(v, dpp<0x118>(NEGV, v));
+  return dpp<0x111>(NEGV, v);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void bwasw_kernel(BwaswArgs a) {
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const uint32_t sid = a.work[blockIdx.x].seed[g];
+  const bool have = sid != BWASW_EMPTY;
+  const BwaswSeed* sp = a.seeds + (have ? sid : 0);
+  uint32_t q_off[2], t_off[2];
+  int qlens[2], tlens[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    q_off[s] = have ? sp->q_off[s] : 0; t_off[s] = have ? sp->t_off[s] : 0;
+    qlens[s] = have ? sp->qlen[s] : 0; tlens[s] = have ? sp->tlen[s] : 0;
+  }
+  const int seed_len = have ? sp->seed_len : 0, seed_qbeg = have ? sp->seed_qbeg : 0;
+  const int end_src = ((lane | 15) << 2);                    // ds_bpermute address of the group's lane 15
+
+  int regScore = seed_len;
+  int qBeg = 0, qEnd = qlens[1], rBeg = 0, rEnd = 0, trueScore = seed_len, score = 0, aw0 = 100, aw1s = 100;
+
+  for (int side = 0; side < 2; side++) {
+    const int qlen = qlens[side], tlen = tlens[side];
+    const int sc0 = regScore, h0 = side == 0 ? seed_len : sc0;
+    const int j0 = l * K - (16 * K - (qlen + 1));            // column of this lane's entry 0 (negative = padding)
+    const uint8_t* qp = a.blob + q_off[side];
+    const uint8_t* tp = a.blob + t_off[side];
+    uint32_t W[K];                                           // nibble t of W = score(t, q) + 4
+    int eh_h[K], eh_e[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int j = j0 + k;
+      const int c = (j >= 0 && j < qlen) ? qp[j] : 4;
+      W[k] = c > 3 ? 0x33333u : (0x30000u | (5u << (4 * c)));
+      eh_h[k] = 0; eh_e[k] = 0;
+    }
+    int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    bool stop = !have;
+    int aw_used = 100;
+
+    for (int bt = 0; bt < 2; bt++) {                         // band tries (:136-272)
+      const bool need = !stop;
+      if (__ballot(need) == 0) break;
+      const int prev = regScore;
+      const int aw_tmp = bt ? 200 : 100;                     // (w_in << k) as uint8_t
+      const int aw1 = aw_tmp < qlen ? aw_tmp : qlen;         // max_ins = max_del = qlen (:600-603)
+      int beg = 0, end = qlen;
+      const int eme0 = imax(h0 - 7, 0);
+      int h1_init = h0 - 6;
+      if (need) {                                            // row 0 reads h0's decay, not the buffer (:175-191)
+        const int end0 = aw1 + 1 < qlen ? aw1 + 1 : qlen;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const int j = j0 + k;
+          if (j >= 0 && j < end0) { eh_h[k] = j == 0 ? h0 : imax(eme0 - (j - 1), 0); eh_e[k] = 0; }
+        }
+      }
+      bool active = need && tlen > 0;
+      int i = 0;
+      uint32_t tw = 0, tw_next = active ? *(const uint32_t*)tp : 0;
+      while (__ballot(active) != 0) {
+        if (active) {
+          if ((i & 3) == 0) { tw = tw_next; tw_next = (i + 4 < tlen) ? *(const uint32_t*)(tp + i + 4) : 0; }
+          const int sh = ((tw >> ((i & 3) * 8)) & 0xFF) * 4;
+          if (beg < i - aw1) beg = i - aw1;
+          if (end > i + aw1 + 1) end = i + aw1 + 1;
+          if (end > qlen) end = qlen;
+          int h1row = 0;
+          if (beg == 0) { h1_init -= 1; h1row = imax(h1_init, 0); }
+          const unsigned span = (unsigned)(end - beg);
+
+          // pass 1: diagonal term, E, local insertion chain
+          int hp[K], en[K];
+          int f = 0;
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            const int j = j0 + k;
+            const bool act = (unsigned)(j - beg) < span;
+            const int M0 = eh_h[k], e = eh_e[k];
+            const int s = (int)__builtin_amdgcn_ubfe(W[k], sh, 4) - 4;
+            const int Mn = M0 ? M0 + s : 0;
+            const int tm = Mn - 7;
+            hp[k] = imax3(Mn, e, f);
+            en[k] = imax3(e - 1, tm, 0);
+            const int fn = imax3(f - 1, tm, 0);
+            f = act ? fn : f;
+          }
+          const int carry = imax(group_exscan_max(f + K * l) - K * (l - 1), 0);   // f entering this lane's first entry
+
+          // pass 2: finish H, shift it into the buffer, row statistics
+          int hk[K];
+#pragma unroll
+          for (int k = 0; k < K; k++) hk[k] = imax(hp[k], carry - k);
+          const int hin = dpp<0x111>(0, hk[K - 1]);              // H(i, j-1) for this lane's entry 0
+          int key = -1, first = 511, last = -1;
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            const int j = j0 + k;
+            const bool act = (unsigned)(j - beg) < span;
+            const bool inr = (unsigned)(j - beg) <= span;        // entries [beg, end]
+            const int hprev = k == 0 ? hin : hk[k - 1];
+            const int nh = j == beg ? h1row : hprev;
+            const int ne = act ? en[k] : 0;                      // entry `end` gets E = 0
+            if (inr) { eh_h[k] = nh; eh_e[k] = ne; }
+            if (act) key = imax(key, (hk[k] << 8) | j);          // last column wins ties (:216)
+            const bool nz = inr && ((nh | ne) != 0);
+            if (nz) last = j;
+            if (nz && act && first == 511) first = j;
+          }
+          key = group_allmax(key);
+          const int pk = group_allmax_pk(((last + 1) << 16) | (512 - first));
+          last = (pk >> 16) - 1; first = 512 - (pk & 0xFFFF);
+          const int m = key < 0 ? 0 : key >> 8, mj = key < 0 ? -1 : (key & 0xFF);
+          if (end == qlen) {                                     // the row reached the query end (:238-243)
+            const int h1 = __builtin_amdgcn_ds_bpermute(end_src, eh_h[K - 1]);
+            if (gscore <= h1) { max_ie = i; gscore = h1; }
+          }
+          if (m == 0) active = false;
+          else {
+            if (m > mx) {
+              mx = m; max_i = i; max_j = mj;
+              const int d = mj > i ? mj - i : i - mj;
+              if (max_off < d) max_off = d;
+            }
+            const int nb = first == 511 ? end : first;           // beg + leading zero entries (:222-228, :263)
+            end = last + 2 < qlen ? last + 2 : qlen;             // end - trailing zero entries + 2 (:229-236, :264)
+            beg = nb;
+            i++;
+            if (i >= tlen) active = false;
+          }
+        }
+      }
+      if (need) {
+        regScore = mx;
+        stop = (mx == prev) || (max_off < (aw_tmp >> 1) + (aw_tmp >> 2));
+        aw_used = aw_tmp;
+      }
+    }
+    if (side == 0) aw0 = aw_used; else aw1s = aw_used;
+    const int qle = max_j + 1, tle = max_i + 1, gtle = max_ie + 1;
+    score = regScore;
+    if (gscore <= 0 || gscore <= regScore - 5) {
+      if (side == 0) { qBeg = seed_qbeg - qle; rBeg = -tle; trueScore = regScore; }
+      else { qEnd = qle; rEnd = tle; trueScore += regScore - sc0; }
+    } else {
+      if (side == 0) { qBeg = 0; rBeg = -gtle; trueScore = gscore; }
+      else { qEnd = qlen; rEnd = gtle; trueScore += gscore - sc0; }
+    }
+  }
+  if (have && l == 0) {
+    const int w = aw0 > aw1s ? aw0 : aw1s;
+    uint4 o;
+    o.x = (uint32_t)(qBeg & 0xFFFF) | ((uint32_t)(qEnd & 0xFFFF) << 16);
+    o.y = (uint32_t)(rBeg & 0xFFFF) | ((uint32_t)(rEnd & 0xFFFF) << 16);
+    o.z = (uint32_t)(score & 0xFFFF) | ((uint32_t)(trueScore & 0xFFFF) << 16);
+    o.w = (uint32_t)(w & 0xFFFF);
+    *(uint4*)(a.out + (size_t)sid * 8) = o;
+  }
+}
+
+}  // namespace
+
+hipError_t bwasw_launch(int K, const BwaswArgs& a, uint32_t n_work, hipStream_t s) {
+  if (n_work == 0) return hipSuccess;
+#define ACCG_BWASW_CASE(k) case k: hipLaunchKernelGGL(bwasw_kernel<k>, dim3(n_work), dim3(64), 0, s, a); break;
+  switch (K) {
+    ACCG_BWASW_CASE(1) ACCG_BWASW_CASE(2) ACCG_BWASW_CASE(3) ACCG_BWASW_CASE(4) ACCG_BWASW_CASE(5) ACCG_BWASW_CASE(6)
+    ACCG_BWASW_CASE(7) ACCG_BWASW_CASE(8) ACCG_BWASW_CASE(9) ACCG_BWASW_CASE(10) ACCG_BWASW_CASE(11) ACCG_BWASW_CASE(12)
+    ACCG_BWASW_CASE(13) ACCG_BWASW_CASE(14) ACCG_BWASW_CASE(15) ACCG_BWASW_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef ACCG_BWASW_CASE
+  return hipGetLastError();
+}
+
+}  // namespace accg

@@ -77,6 +77,13 @@ def load():
     L.accg_smem_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_smem_batch_results.argtypes = [vp, vp, vp]
     L.accg_smem_batch_destroy.argtypes = [vp]
+    L.accg_bwasw_batch_create.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(vp)]
+    L.accg_bwasw_batch_cells.restype = C.c_uint64
+    L.accg_bwasw_batch_cells.argtypes = [vp]
+    L.accg_bwasw_batch_run.argtypes = [vp]
+    L.accg_bwasw_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.accg_bwasw_batch_results.argtypes = [vp, vp, vp]
+    L.accg_bwasw_batch_destroy.argtypes = [vp]
     L.accg_phmm_tables_f32.argtypes = [vp, vp, vp, vp]
     L.accg_phmm_tables_f64.argtypes = [vp, vp, vp, vp]
     _lib = L
@@ -290,6 +297,49 @@ class SmemBatch:
     def close(self):
         if self.h:
             self.L.accg_smem_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class BwaswBatch:
+    """Device-resident batch of BWA-MEM seeds to extend (accg_bwasw_batch_*).
+
+    seqs uint8 codes, seq_off uint32[n] (start of [left query][right query][left target][right target] per seed),
+    params uint16[n, 7] = {leftQlen, leftRlen, rightQlen, rightRlen, seed_len, seed_qbeg, seed_index}."""
+
+    def __init__(self, ctx, seqs, seq_off, params):
+        self.L = ctx.L
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(seq_off, dtype=np.uint32)
+        par = np.ascontiguousarray(params, dtype=np.uint16).reshape(-1, 7)
+        self.n = int(len(off))
+        self.h = C.c_void_p()
+        _check(self.L.accg_bwasw_batch_create(ctx.h, self.n, seqs.ctypes.data, off.ctypes.data, par.ctypes.data, C.byref(self.h)))
+        self.cells = int(self.L.accg_bwasw_batch_cells(self.h))
+
+    def run(self):
+        _check(self.L.accg_bwasw_batch_run(self.h))
+
+    def time(self, warmup=1, iters=3):
+        ms = C.c_float()
+        _check(self.L.accg_bwasw_batch_time(self.h, warmup, iters, C.byref(ms)))
+        return ms.value
+
+    def results(self):
+        """(fields int16[n, 7] = qBeg, qEnd, rBeg, rEnd, score, trueScore, width; words int32[n, 5])"""
+        f = np.zeros((self.n, 7), np.int16)
+        w = np.zeros((self.n, 5), np.int32)
+        _check(self.L.accg_bwasw_batch_results(self.h, f.ctypes.data, w.ctypes.data))
+        return f, w
+
+    def close(self):
+        if self.h:
+            self.L.accg_bwasw_batch_destroy(self.h)
             self.h = C.c_void_p()
 
     def __enter__(self):

@@ -146,3 +146,50 @@ def deserialize_haps(buf):
         ln = int(np.frombuffer(b, np.int32, 1, p)[0]); p += 4
         out.append(b[p:p + ln]); p += ln
     return out
+
+
+def make_bwasw_seeds(rng, n, read_len=150, sub_rate=0.02, indel_frac=0.15, n_frac=0.002, min_seed=19, max_seed=60):
+    """Seed-extension tasks shaped like BWA-MEM's (mem_chain2aln): a read sampled from a reference window with
+    substitutions and, for a fraction of reads, one short indel; one exact seed per task; the left side reversed, target
+    lengths = query length + cal_max_gap.  Returns (seqs uint8, seq_off uint32[n], params uint16[n, 7])."""
+    flank = read_len + 210
+    win = rng.integers(0, 4, size=(n, read_len + 2 * flank), dtype=np.uint8)
+    reads = win[:, flank:flank + read_len].copy()
+    sub = rng.random(reads.shape) < sub_rate
+    reads[sub] = (reads[sub] + rng.integers(1, 4, size=int(sub.sum()), dtype=np.uint8)) & 3
+    if n_frac > 0:
+        reads[rng.random(reads.shape) < n_frac] = 4
+    seed_len = rng.integers(min(min_seed, read_len), min(max_seed, read_len) + 1, size=n)
+    qbeg = (rng.random(n) * (read_len - seed_len + 1)).astype(np.int64)
+    has_indel = rng.random(n) < indel_frac
+    max_gap = lambda q: np.where(q > 0, np.clip((q - 6) // 1 + 1, 1, 200), 0)
+    lq = qbeg; rq = read_len - qbeg - seed_len
+    lr = lq + max_gap(lq); rr = rq + max_gap(rq)
+    tot = lq + rq + lr + rr
+    off = np.zeros(n, np.uint32); off[1:] = np.cumsum(tot)[:-1]
+    seqs = np.empty(int(tot.sum()) + 8, np.uint8)
+    par = np.stack([lq, lr, rq, rr, seed_len, qbeg, np.arange(n) & 0xFFFF], axis=1).astype(np.uint16)
+    for i in range(n):
+        r = reads[i]
+        a, sl = int(qbeg[i]), int(seed_len[i])
+        if has_indel[i]:
+            side_right = rq[i] > lq[i]
+            seg = r[a + sl:] if side_right else r[:a]
+            if len(seg) > 12:
+                p = int(rng.integers(4, len(seg) - 6)); d = int(rng.integers(1, 6))
+                if rng.random() < 0.5:   # deletion from the read, refill at the far end
+                    fill = rng.integers(0, 4, size=d, dtype=np.uint8)
+                    seg2 = np.concatenate([seg[:p], seg[p + d:], fill]) if side_right else np.concatenate([fill, seg[:p], seg[p + d:]])
+                else:                    # insertion into the read, drop from the far end
+                    ins = rng.integers(0, 4, size=d, dtype=np.uint8)
+                    seg2 = np.concatenate([seg[:p], ins, seg[p:]])
+                    seg2 = seg2[:len(seg)] if side_right else seg2[d:]
+                r = r.copy()
+                if side_right: r[a + sl:] = seg2
+                else: r[:a] = seg2
+        o = int(off[i])
+        seqs[o:o + lq[i]] = r[:a][::-1]; o += int(lq[i])
+        seqs[o:o + rq[i]] = r[a + sl:]; o += int(rq[i])
+        seqs[o:o + lr[i]] = win[i, flank + a - int(lr[i]):flank + a][::-1]; o += int(lr[i])
+        seqs[o:o + rr[i]] = win[i, flank + a + sl:flank + a + sl + int(rr[i])]
+    return seqs, off, par

@@ -149,6 +149,26 @@ int accg_smem_batch_time(accg_smem_batch* b, int warmup, int iters, float* ms_pe
 int accg_smem_batch_results(accg_smem_batch* b, void* mem_output, int32_t* mem_num);
 void accg_smem_batch_destroy(accg_smem_batch* b);
 
+/* ---- BWA-MEM seed extension (bwa-sw) ---------------------------------------------------------------------
+ * seed_proc + sw_extend of the reference's FPGA kernel (bwa-sw/sdaccel/smithwaterman.cpp:511-672, :75-273): for each seed
+ * a banded left extension, then a right extension seeded with the left score (match 1, mismatch -4, N -1, gap 6+1,
+ * pen_clip 5, w 100, up to two band tries).  Inputs are the two streams the FPGA host feeds (:564-584): per seed
+ * params = {leftQlen, leftRlen, rightQlen, rightRlen, seed_len, seed_qbeg, seed_index} (uint16 x 7) and the codes (0-3,
+ * >= 4 = N) [left query][right query][left target][right target] at seqs + seq_off[i].  Results: fields = int16[n][7]
+ * {qBeg, qEnd, rBeg, rEnd, score, trueScore, width} and/or words = int32[n][5], the match stream of :666-670.
+ * Limits are the device code's own (uint8_t qlen, uint11_t tlen, seq_mem[2048]).  PARITY of this path is unpinned (see
+ * DESIGN.md): the reference is HLS device code and its host needs libbwa; neither builds here. */
+#define ACCG_BWASW_MAX_QLEN 254
+#define ACCG_BWASW_MAX_TLEN 2047
+typedef struct accg_bwasw_batch accg_bwasw_batch;
+int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const uint8_t* seqs, const uint32_t* seq_off, const uint16_t* params,
+                            accg_bwasw_batch** out);
+uint64_t accg_bwasw_batch_cells(const accg_bwasw_batch* b);
+int accg_bwasw_batch_run(accg_bwasw_batch* b);
+int accg_bwasw_batch_time(accg_bwasw_batch* b, int warmup, int iters, float* ms_per_run);
+int accg_bwasw_batch_results(accg_bwasw_batch* b, int16_t* fields, int32_t* words);
+void accg_bwasw_batch_destroy(accg_bwasw_batch* b);
+
 /* ---- counters (multi-GPU) ---------------------------------------------------------------------
  * Packs counters into the uint64[4] {cells, pairs, kernel_ns, rescued} vector that the ranks
  * all-reduce over RCCL; the collective itself is issued by the host harness

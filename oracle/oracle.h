@@ -78,6 +78,10 @@ void orc_smem_batch(const uint32_t* bwt, const uint64_t* para, const uint8_t* se
 uint64_t orc_smem_last_lookups(void);   /* 64-byte index blocks requested by the last orc_smem_batch */
 void orc_smem_occ4(const uint32_t* bwt, const uint64_t* para, uint64_t k, uint64_t cnt[4]);
 
+/* ---- BWA-MEM seed extension (PARITY UNPINNED, see bwasw_oracle.c) ------------------------------------------------ */
+void orc_bwasw_batch(const uint8_t* seqs, const uint32_t* seq_off, const uint16_t* params, int n, int16_t* out, int n_threads);
+void orc_bwasw_extend(const uint8_t* q, int qlen, const uint8_t* t, int tlen, int h0, int out[7]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ def _load(path):
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("phmm_oracle.c", "sw_oracle.c", "smem_oracle.c", "oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("phmm_oracle.c", "sw_oracle.c", "smem_oracle.c", "bwasw_oracle.c", "oracle.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -59,6 +59,8 @@ def oracle():
         L.orc_sw_pair.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int] * 7 + [i32p, i32p, i32p, C.c_int, i32p, i32p, i32p]
         L.orc_sw_score_many.argtypes = [C.c_char_p, C.c_int, i32p, C.c_char_p, C.c_int, i32p] + [C.c_int] * 6 + [i32p, i32p, i32p, C.c_int]
         L.orc_smem_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_bwasw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_bwasw_extend.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_smem_last_lookups.restype = C.c_uint64
         L.orc_smem_occ4.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _oracle = L

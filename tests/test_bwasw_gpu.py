@@ -1,0 +1,108 @@
+"""BWA-MEM seed extension on the GPU (accg_bwasw_batch_*) against oracle/bwasw_oracle.c, bit-exact.
+PARITY UNPINNED for this path: the oracle restates FPGA device code that cannot be built here."""
+import numpy as np
+import pytest
+
+import orc
+import acc_genomics_amd as A
+from acc_genomics_amd import synth
+from acc_genomics_amd.lib import AccgError, BwaswBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = A.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle(seqs, off, par, threads=8):
+    O = orc.oracle()
+    out = np.zeros((len(off), 7), np.int16)
+    O.orc_bwasw_batch(seqs.ctypes.data, off.ctypes.data, par.ctypes.data, len(off), out.ctypes.data, threads)
+    return out
+
+
+def _check(ctx, seqs, off, par):
+    want = _oracle(seqs, off, par)
+    with BwaswBatch(ctx, seqs, off, par) as b:
+        b.run()
+        got, words = b.results()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], got[bad[:3]], want[bad[:3]], par[bad[:3]])
+    assert (words[:, 0] == par[:, 6]).all()
+    assert ((words[:, 1] & 0xFFFF).astype(np.uint16).view(np.int16) == want[:, 0]).all()
+    assert ((words[:, 3] >> 16).astype(np.int16) == want[:, 5]).all()
+    return got
+
+
+def test_bwamem_like_seeds(ctx):
+    rng = np.random.default_rng(41)
+    seqs, off, par = synth.make_bwasw_seeds(rng, 6000, read_len=150)
+    got = _check(ctx, seqs, off, par)
+    assert (got[:, 5] >= par[:, 4].astype(np.int16)).all()
+
+
+@pytest.mark.parametrize("read_len,sub,indel", [(36, 0.05, 0.3), (101, 0.10, 0.5), (250, 0.03, 0.5), (273, 0.01, 0.2)])
+def test_lengths_and_divergence(ctx, read_len, sub, indel):
+    rng = np.random.default_rng(read_len)
+    seqs, off, par = synth.make_bwasw_seeds(rng, 1500, read_len=read_len, sub_rate=sub, indel_frac=indel, n_frac=0.01)
+    _check(ctx, seqs, off, par)
+
+
+def test_random_unrelated_and_edges(ctx):
+    """Unrelated sequences (extension dies at once), empty sides, maximum query length, long targets."""
+    rng = np.random.default_rng(43)
+    seqs, offs, pars = [], [], []
+    pos = 0
+    shapes = [(0, 0, 0, 0), (0, 5, 0, 7), (5, 0, 7, 0), (254, 400, 1, 3), (1, 1, 254, 508), (100, 1200, 100, 300), (16, 40, 15, 31),
+              (17, 17, 31, 33), (32, 64, 47, 48)]
+    for k in range(400):
+        lq, lr, rq, rr = shapes[k] if k < len(shapes) else (int(rng.integers(0, 120)), int(rng.integers(0, 260)),
+                                                             int(rng.integers(0, 120)), int(rng.integers(0, 260)))
+        related = rng.random() < 0.6
+        def side(ql, tl):
+            t = rng.integers(0, 4, size=tl).astype(np.uint8)
+            q = rng.integers(0, 4, size=ql).astype(np.uint8)
+            if related:
+                m = min(ql, tl); q[:m] = t[:m]
+                mut = rng.random(ql) < 0.06
+                q[mut] = rng.integers(0, 5, size=int(mut.sum()))
+            return q, t
+        q0, t0 = side(lq, lr); q1, t1 = side(rq, rr)
+        s = np.concatenate([q0, q1, t0, t1]).astype(np.uint8)
+        seqs.append(s); offs.append(pos); pos += len(s)
+        pars.append([lq, lr, rq, rr, int(rng.integers(1, 100)), lq, k])
+    seq = np.concatenate(seqs + [np.zeros(4, np.uint8)])
+    _check(ctx, seq, np.array(offs, np.uint32), np.array(pars, np.uint16))
+
+
+def test_second_band_try(ctx):
+    """A 90-base deletion near the seed makes max_off exceed 3/4 of the first band, so the w = 200 retry runs."""
+    rng = np.random.default_rng(44)
+    seqs, offs, pars = [], [], []
+    pos = 0
+    for k in range(64):
+        ql = int(rng.integers(200, 255)); gap = int(rng.integers(76, 100)); p = int(rng.integers(20, 60))
+        q = rng.integers(0, 4, size=ql).astype(np.uint8)
+        t = np.concatenate([q[:p], rng.integers(0, 4, size=gap).astype(np.uint8), q[p:], rng.integers(0, 4, size=20).astype(np.uint8)])
+        s = np.concatenate([np.zeros(0, np.uint8), q, np.zeros(0, np.uint8), t]).astype(np.uint8)   # right side only
+        seqs.append(s); offs.append(pos); pos += len(s)
+        pars.append([0, 0, ql, len(t), 120, 0, k])
+    seq = np.concatenate(seqs)
+    off = np.array(offs, np.uint32); par = np.array(pars, np.uint16)
+    got = _check(ctx, seq, off, par)
+    assert (got[:, 6] == 200).any()
+
+
+def test_empty_batch_and_limits(ctx):
+    with BwaswBatch(ctx, np.zeros(4, np.uint8), np.zeros(0, np.uint32), np.zeros((0, 7), np.uint16)) as b:
+        b.run()
+        f, w = b.results()
+        assert f.shape == (0, 7)
+    with pytest.raises(AccgError):
+        BwaswBatch(ctx, np.zeros(600, np.uint8), np.zeros(1, np.uint32), np.array([[255, 10, 0, 0, 19, 255, 0]], np.uint16))
+    with pytest.raises(AccgError):
+        BwaswBatch(ctx, np.zeros(4000, np.uint8), np.zeros(1, np.uint32), np.array([[10, 2048, 0, 0, 19, 10, 0]], np.uint16))
