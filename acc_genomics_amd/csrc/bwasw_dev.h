@@ -16,7 +16,7 @@ struct alignas(16) BwaswSeed {           // one seed = left extension then right
   uint32_t pad_;
 };
 
-struct BwaswWork { uint32_t seed[4]; };  // one wavefront = four seeds, 16 lanes each
+struct BwaswWork { uint32_t seed[4]; };  // one wavefront = one side of four seeds, 16 lanes each
 
 struct BwaswArgs {
   const uint8_t* blob;                   // codes 0-3, 4 = N; padded so a 4-byte read at any target offset stays inside
@@ -25,6 +25,6 @@ struct BwaswArgs {
   int16_t* out;                          // n_seeds x 8: qBeg, qEnd, rBeg, rEnd, score, trueScore, width, 0
 };
 
-hipError_t bwasw_launch(int K, const BwaswArgs& a, uint32_t n_work, hipStream_t s);
+hipError_t bwasw_launch(int K, int side, const BwaswArgs& a, uint32_t n_work, hipStream_t s);
 
 }  // namespace accg

@@ -18,10 +18,20 @@ struct accg_bwasw_batch {
   BwaswWork* d_work = nullptr;
   int16_t* d_out = nullptr;
   std::vector<uint16_t> seed_index;                      // echoed into the packed result words
-  struct Launch { int K; uint32_t work_off, n_work; };
+  struct Launch { int K, side; uint32_t work_off, n_work; };
   std::vector<Launch> launches;
   uint64_t cells = 0;
-  ~accg_bwasw_batch() { for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) hipFree(p); }
+  // The K classes of one side are independent kernels whose wavefronts run for hundreds of microseconds: queued on one stream
+  // every launch would wait for the previous one to drain.  They are spread over a few streams forked from / joined to the
+  // context's stream instead; the right-side pass forks after the left-side pass has joined.
+  static constexpr int N_AUX = 4;
+  hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+  ~accg_bwasw_batch() {
+    for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) hipFree(p);
+    for (int i = 0; i < N_AUX; i++) { if (aux[i]) hipStreamDestroy(aux[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
+    if (ev_fork) hipEventDestroy(ev_fork);
+  }
 };
 
 extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const uint8_t* seqs, const uint32_t* seq_off,
@@ -32,8 +42,6 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
   std::unique_ptr<accg_bwasw_batch> b(new accg_bwasw_batch);
   b->ctx = ctx; b->n = n_seeds;
   std::vector<BwaswSeed> seeds(n_seeds);
-  std::vector<int> kclass(n_seeds);
-  std::vector<uint32_t> rows(n_seeds);
   b->seed_index.resize(n_seeds);
   size_t blob_bytes = 0;
   for (uint32_t i = 0; i < n_seeds; i++) {
@@ -52,9 +60,6 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
     s.t_off[0] = (uint32_t)blob_bytes;               blob_bytes += (p[1] + 3u) & ~3u;
     s.t_off[1] = (uint32_t)blob_bytes;               blob_bytes += (p[3] + 3u) & ~3u;
     if (blob_bytes > 0xFFFFFFF0ull) return ACCG_ERR_TOO_LONG;
-    const int ql = std::max<int>(p[0], p[2]);
-    kclass[i] = (ql + 1 + 15) / 16;
-    rows[i] = (uint32_t)p[1] + p[3];
     b->cells += (uint64_t)p[0] * p[1] + (uint64_t)p[2] * p[3];
   }
   std::vector<uint8_t> blob(blob_bytes + 16, 4);
@@ -68,26 +73,36 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
       src += len[part];
     }
   }
-  // four seeds per wavefront: same K, similar row counts (a wavefront runs as long as its longest seed)
-  std::vector<uint32_t> order(n_seeds);
-  std::iota(order.begin(), order.end(), 0u);
-  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-    if (kclass[x] != kclass[y]) return kclass[x] > kclass[y];
-    if (rows[x] != rows[y]) return rows[x] > rows[y];
-    return x < y;
-  });
+  // one side of four seeds per wavefront: same K, similar target lengths (a wavefront runs as long as its longest member);
+  // every left pass is queued before the right passes that read its records
   std::vector<BwaswWork> work;
-  for (uint32_t i = 0; i < n_seeds;) {
-    const int K = kclass[order[i]];
-    accg_bwasw_batch::Launch L{K, (uint32_t)work.size(), 0};
-    while (i < n_seeds && kclass[order[i]] == K) {
-      BwaswWork w;
-      for (int g = 0; g < 4; g++) w.seed[g] = (i < n_seeds && kclass[order[i]] == K) ? order[i++] : BWASW_EMPTY;
-      work.push_back(w);
-      L.n_work++;
+  std::vector<uint32_t> order(n_seeds);
+  for (int side = 0; side < 2; side++) {
+    auto kclass = [&](uint32_t x) { return (seeds[x].qlen[side] + 1 + 15) / 16; };
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      const int kx = kclass(x), ky = kclass(y);
+      if (kx != ky) return kx > ky;
+      if (seeds[x].tlen[side] != seeds[y].tlen[side]) return seeds[x].tlen[side] > seeds[y].tlen[side];
+      return x < y;
+    });
+    for (uint32_t i = 0; i < n_seeds;) {
+      const int K = kclass(order[i]);
+      accg_bwasw_batch::Launch L{K, side, (uint32_t)work.size(), 0};
+      while (i < n_seeds && kclass(order[i]) == K) {
+        BwaswWork w;
+        for (int g = 0; g < 4; g++) w.seed[g] = (i < n_seeds && kclass(order[i]) == K) ? order[i++] : BWASW_EMPTY;
+        work.push_back(w);
+        L.n_work++;
+      }
+      b->launches.push_back(L);
     }
-    b->launches.push_back(L);
   }
+  for (int i = 0; i < accg_bwasw_batch::N_AUX; i++) {
+    ACCG_HIP(hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking));
+    ACCG_HIP(hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming));
+  }
+  ACCG_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
   ACCG_HIP(hipMalloc((void**)&b->d_blob, blob.size()));
   ACCG_HIP(hipMalloc((void**)&b->d_seeds, std::max<size_t>(n_seeds, 1) * sizeof(BwaswSeed)));
   ACCG_HIP(hipMalloc((void**)&b->d_work, std::max<size_t>(work.size(), 1) * sizeof(BwaswWork)));
@@ -107,9 +122,20 @@ extern "C" int accg_bwasw_batch_run(accg_bwasw_batch* b) {
   ACCG_HIP(hipSetDevice(b->ctx->device));
   BwaswArgs a;
   a.blob = b->d_blob; a.seeds = b->d_seeds; a.out = b->d_out;
-  for (const auto& L : b->launches) {
-    a.work = b->d_work + L.work_off;
-    ACCG_HIP(bwasw_launch(L.K, a, L.n_work, b->ctx->stream));
+  hipStream_t main = b->ctx->stream;
+  for (int side = 0; side < 2; side++) {
+    ACCG_HIP(hipEventRecord(b->ev_fork, main));
+    for (int i = 0; i < accg_bwasw_batch::N_AUX; i++) ACCG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+    int rr = 0;
+    for (const auto& L : b->launches) {
+      if (L.side != side) continue;
+      a.work = b->d_work + L.work_off;
+      ACCG_HIP(bwasw_launch(L.K, L.side, a, L.n_work, b->aux[rr++ % accg_bwasw_batch::N_AUX]));
+    }
+    for (int i = 0; i < accg_bwasw_batch::N_AUX; i++) {
+      ACCG_HIP(hipEventRecord(b->ev_join[i], b->aux[i]));
+      ACCG_HIP(hipStreamWaitEvent(main, b->ev_join[i], 0));
+    }
   }
   return ACCG_OK;
 }

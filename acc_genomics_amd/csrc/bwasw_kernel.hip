@@ -52,39 +52,48 @@ __device__ __forceinline__ int group_exscan_max(int v) {
   return dpp<0x111>(NEGV, v);
 }
 
-template <int K>
+// SIDE 0 = left extension (writes its partial result into the seed's output record), SIDE 1 = right extension (reads it back
+// and finishes the record).  Two passes let each side run with the K and the row count of its own query/target.
+template <int K, int SIDE>
 __global__ __launch_bounds__(64) void bwasw_kernel(BwaswArgs a) {
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
   const uint32_t sid = a.work[blockIdx.x].seed[g];
   const bool have = sid != BWASW_EMPTY;
   const BwaswSeed* sp = a.seeds + (have ? sid : 0);
-  uint32_t q_off[2], t_off[2];
-  int qlens[2], tlens[2];
-#pragma unroll
-  for (int s = 0; s < 2; s++) {
-    q_off[s] = have ? sp->q_off[s] : 0; t_off[s] = have ? sp->t_off[s] : 0;
-    qlens[s] = have ? sp->qlen[s] : 0; tlens[s] = have ? sp->tlen[s] : 0;
-  }
+  const uint32_t q_off = have ? sp->q_off[SIDE] : 0, t_off = have ? sp->t_off[SIDE] : 0;
+  const int qlen = have ? sp->qlen[SIDE] : 0, tlen = have ? sp->tlen[SIDE] : 0;
   const int seed_len = have ? sp->seed_len : 0, seed_qbeg = have ? sp->seed_qbeg : 0;
   const int end_src = ((lane | 15) << 2);                    // ds_bpermute address of the group's lane 15
+  int16_t* rec = a.out + (size_t)(have ? sid : 0) * 8;
 
   int regScore = seed_len;
-  int qBeg = 0, qEnd = qlens[1], rBeg = 0, rEnd = 0, trueScore = seed_len, score = 0, aw0 = 100, aw1s = 100;
+  int qBeg = 0, qEnd = qlen, rBeg = 0, rEnd = 0, trueScore = seed_len, score = 0, aw0 = 100, aw1s = 100;
+  if (SIDE == 1 && have) {                                   // the left pass left {qBeg, -, rBeg, -, regScore, trueScore, aw[0], -}
+    const uint4 r = *(const uint4*)rec;
+    qBeg = (int16_t)(r.x & 0xFFFF); rBeg = (int16_t)(r.y & 0xFFFF);
+    regScore = (int16_t)(r.z & 0xFFFF); trueScore = (int16_t)(r.z >> 16); aw0 = (int16_t)(r.w & 0xFFFF);
+  }
 
-  for (int side = 0; side < 2; side++) {
-    const int qlen = qlens[side], tlen = tlens[side];
+  {
+    constexpr int side = SIDE;
     const int sc0 = regScore, h0 = side == 0 ? seed_len : sc0;
     const int j0 = l * K - (16 * K - (qlen + 1));            // column of this lane's entry 0 (negative = padding)
-    const uint8_t* qp = a.blob + q_off[side];
-    const uint8_t* tp = a.blob + t_off[side];
+    const uint8_t* qp = a.blob + q_off;
+    const uint8_t* tp = a.blob + t_off;
     uint32_t W[K];                                           // nibble t of W = score(t, q) + 4
     int eh_h[K], eh_e[K];
+    // The device code never clears eh[] between band tries, so the second try (w = 200) can read, right of column 200, what
+    // the first try left behind -- including entries this kernel zeroes when the band limit steps over them.  Only queries
+    // longer than 201 can see that; for those (K >= 13) the stepped-over values are kept aside and put back.
+    constexpr bool STASH = K >= 13;
+    int st_h[STASH ? K : 1], st_e[STASH ? K : 1];
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int j = j0 + k;
       const int c = (j >= 0 && j < qlen) ? qp[j] : 4;
       W[k] = c > 3 ? 0x33333u : (0x30000u | (5u << (4 * c)));
       eh_h[k] = 0; eh_e[k] = 0;
+      if constexpr (STASH) { st_h[k] = 0; st_e[k] = 0; }
     }
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     bool stop = !have;
@@ -105,6 +114,9 @@ __global__ __launch_bounds__(64) void bwasw_kernel(BwaswArgs a) {
         for (int k = 0; k < K; k++) {
           const int j = j0 + k;
           if (j >= 0 && j < end0) { eh_h[k] = j == 0 ? h0 : imax(eme0 - (j - 1), 0); eh_e[k] = 0; }
+          else if constexpr (STASH) {
+            if (bt == 1 && (st_h[k] | st_e[k]) != 0) { eh_h[k] = st_h[k]; eh_e[k] = st_e[k]; }
+          }
         }
       }
       bool active = need && tlen > 0;
@@ -114,54 +126,67 @@ __global__ __launch_bounds__(64) void bwasw_kernel(BwaswArgs a) {
         if (active) {
           if ((i & 3) == 0) { tw = tw_next; tw_next = (i + 4 < tlen) ? *(const uint32_t*)(tp + i + 4) : 0; }
           const int sh = ((tw >> ((i & 3) * 8)) & 0xFF) * 4;
-          if (beg < i - aw1) beg = i - aw1;
+          if (beg < i - aw1) {                                   // the band limit may step over live entries (:151): clear them,
+            const int kb0 = beg - j0, kb1 = i - aw1 - j0;          // the row code relies on "everything left of beg is zero"
+#pragma unroll
+            for (int k = 0; k < K; k++)
+              if (k >= kb0 && k < kb1) {
+                if constexpr (STASH) { st_h[k] = eh_h[k]; st_e[k] = eh_e[k]; }
+                eh_h[k] = 0; eh_e[k] = 0;
+              }
+            beg = i - aw1;
+          }
           if (end > i + aw1 + 1) end = i + aw1 + 1;
           if (end > qlen) end = qlen;
           int h1row = 0;
           if (beg == 0) { h1_init -= 1; h1row = imax(h1_init, 0); }
-          const unsigned span = (unsigned)(end - beg);
+          const int kb = beg - j0, ke = end - j0;                // this lane's entries [kb, ke) are inside the band
 
-          // pass 1: diagonal term, E, local insertion chain
+          // pass 1: diagonal term, E, local insertion chain.  No band mask is needed here: entries left of beg are zero, so
+          // they produce H = E = F = 0, and whatever is computed right of end is never stored.
           int hp[K], en[K];
           int f = 0;
 #pragma unroll
           for (int k = 0; k < K; k++) {
-            const int j = j0 + k;
-            const bool act = (unsigned)(j - beg) < span;
             const int M0 = eh_h[k], e = eh_e[k];
             const int s = (int)__builtin_amdgcn_ubfe(W[k], sh, 4) - 4;
             const int Mn = M0 ? M0 + s : 0;
             const int tm = Mn - 7;
             hp[k] = imax3(Mn, e, f);
             en[k] = imax3(e - 1, tm, 0);
-            const int fn = imax3(f - 1, tm, 0);
-            f = act ? fn : f;
+            f = imax3(f - 1, tm, 0);
           }
           const int carry = imax(group_exscan_max(f + K * l) - K * (l - 1), 0);   // f entering this lane's first entry
 
-          // pass 2: finish H, shift it into the buffer, row statistics
+          // pass 2: finish H, shift it into the buffer, row statistics (positions as k, converted to columns afterwards)
           int hk[K];
 #pragma unroll
           for (int k = 0; k < K; k++) hk[k] = imax(hp[k], carry - k);
           const int hin = dpp<0x111>(0, hk[K - 1]);              // H(i, j-1) for this lane's entry 0
-          int key = -1, first = 511, last = -1;
+          int key = -1, firstk = -1, lastk = -1;
+          bool nzl[K];
 #pragma unroll
           for (int k = 0; k < K; k++) {
-            const int j = j0 + k;
-            const bool act = (unsigned)(j - beg) < span;
-            const bool inr = (unsigned)(j - beg) <= span;        // entries [beg, end]
+            const bool lt = k < ke, le = k <= ke;                // entries [.., end) / [.., end]
             const int hprev = k == 0 ? hin : hk[k - 1];
-            const int nh = j == beg ? h1row : hprev;
-            const int ne = act ? en[k] : 0;                      // entry `end` gets E = 0
-            if (inr) { eh_h[k] = nh; eh_e[k] = ne; }
-            if (act) key = imax(key, (hk[k] << 8) | j);          // last column wins ties (:216)
-            const bool nz = inr && ((nh | ne) != 0);
-            if (nz) last = j;
-            if (nz && act && first == 511) first = j;
+            const int nh = k == kb ? h1row : hprev;
+            const int ne = lt ? en[k] : 0;                       // entry `end` gets E = 0
+            if (le) { eh_h[k] = nh; eh_e[k] = ne; }
+            key = imax(key, ((lt ? hk[k] : -1) << 4) | k);       // last column wins ties (:216)
+            const bool nz = le && ((nh | ne) != 0);
+            if (nz) lastk = k;
+            nzl[k] = nz && lt;
           }
+#pragma unroll
+          for (int k = K - 1; k >= 0; k--)
+            if (nzl[k]) firstk = k;
+          const int first_l = firstk < 0 ? 511 : j0 + firstk;
+          int last = lastk < 0 ? -1 : j0 + lastk;
+          key = key < 0 ? -1 : (((key >> 4) << 8) | (j0 + (key & 15)));
           key = group_allmax(key);
-          const int pk = group_allmax_pk(((last + 1) << 16) | (512 - first));
-          last = (pk >> 16) - 1; first = 512 - (pk & 0xFFFF);
+          const int pk = group_allmax_pk(((last + 1) << 16) | (512 - first_l));
+          last = (pk >> 16) - 1;
+          const int first = 512 - (pk & 0xFFFF);
           const int m = key < 0 ? 0 : key >> 8, mj = key < 0 ? -1 : (key & 0xFF);
           if (end == qlen) {                                     // the row reached the query end (:238-243)
             const int h1 = __builtin_amdgcn_ds_bpermute(end_src, eh_h[K - 1]);
@@ -200,21 +225,24 @@ __global__ __launch_bounds__(64) void bwasw_kernel(BwaswArgs a) {
     }
   }
   if (have && l == 0) {
-    const int w = aw0 > aw1s ? aw0 : aw1s;
+    const int w = SIDE == 0 ? aw0 : (aw0 > aw1s ? aw0 : aw1s);
     uint4 o;
     o.x = (uint32_t)(qBeg & 0xFFFF) | ((uint32_t)(qEnd & 0xFFFF) << 16);
     o.y = (uint32_t)(rBeg & 0xFFFF) | ((uint32_t)(rEnd & 0xFFFF) << 16);
     o.z = (uint32_t)(score & 0xFFFF) | ((uint32_t)(trueScore & 0xFFFF) << 16);
     o.w = (uint32_t)(w & 0xFFFF);
-    *(uint4*)(a.out + (size_t)sid * 8) = o;
+    *(uint4*)rec = o;
   }
 }
 
 }  // namespace
 
-hipError_t bwasw_launch(int K, const BwaswArgs& a, uint32_t n_work, hipStream_t s) {
+hipError_t bwasw_launch(int K, int side, const BwaswArgs& a, uint32_t n_work, hipStream_t s) {
   if (n_work == 0) return hipSuccess;
-#define ACCG_BWASW_CASE(k) case k: hipLaunchKernelGGL(bwasw_kernel<k>, dim3(n_work), dim3(64), 0, s, a); break;
+#define ACCG_BWASW_CASE(k) case k: \
+    if (side == 0) hipLaunchKernelGGL((bwasw_kernel<k, 0>), dim3(n_work), dim3(64), 0, s, a); \
+    else hipLaunchKernelGGL((bwasw_kernel<k, 1>), dim3(n_work), dim3(64), 0, s, a); \
+    break;
   switch (K) {
     ACCG_BWASW_CASE(1) ACCG_BWASW_CASE(2) ACCG_BWASW_CASE(3) ACCG_BWASW_CASE(4) ACCG_BWASW_CASE(5) ACCG_BWASW_CASE(6)
     ACCG_BWASW_CASE(7) ACCG_BWASW_CASE(8) ACCG_BWASW_CASE(9) ACCG_BWASW_CASE(10) ACCG_BWASW_CASE(11) ACCG_BWASW_CASE(12)

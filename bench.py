@@ -242,6 +242,48 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
     return reads_done, t1 - t0, extras
 
 
+def bench_bwasw(ctx, rank, dist, torch, steps, with_cpu, n_seeds=1 << 18):
+    """Seed-extension leg (bwa-sw): n_seeds BWA-MEM-shaped extension tasks from 150-bp reads."""
+    import acc_genomics_amd as A
+    from acc_genomics_amd import synth
+    rng = synth.rng_for(5 + 1000 * rank)
+    seqs, off, par = synth.make_bwasw_seeds(rng, n_seeds, read_len=150)
+    b = A.BwaswBatch(ctx, seqs, off, par)
+    b.run()
+    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h))
+    stream.synchronize(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    stream.synchronize(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    extras = None
+    if rank == 0:
+        k_ms = b.time(warmup=0, iters=max(2, steps))
+        cpu = None
+        if with_cpu:
+            import orc
+            O = orc.oracle()
+            S = min(n_seeds, 16384)
+            th = host_cores()
+            out = np.zeros((S, 7), np.int16)
+            c0 = time.perf_counter()
+            O.orc_bwasw_batch(seqs.ctypes.data, off.ctypes.data, par.ctypes.data, S, out.ctypes.data, th)
+            dt = time.perf_counter() - c0
+            cpu = {"value": S / dt / 1e6, "unit": "Mseeds/s", "cores": th, "kind": "port",
+                   "sample": "%d seeds through oracle/bwasw_oracle.c (restatement of bwa-sw/sdaccel/smithwaterman.cpp, FPGA device code "
+                             "that cannot be built here), %.2f s wall" % (S, dt)}
+        extras = {"kernel_ms": k_ms, "seeds_per_gpu": n_seeds, "rect_cells_per_gpu": b.cells, "cpu_baseline": cpu,
+                  "note": "VALU-issue bound integer recurrence held in registers; HBM traffic is the sequences once (%d bytes)" % len(seqs)}
+    done = n_seeds * steps
+    b.close()
+    return done, t1 - t0, extras
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +293,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sw-steps", type=int, default=5, help="passes over the Smith-Waterman batch (0 = skip that leg)")
     ap.add_argument("--smem-steps", type=int, default=3, help="passes over the SMEM read batch (0 = skip that leg)")
+    ap.add_argument("--bwasw-steps", type=int, default=3, help="passes over the seed-extension batch (0 = skip that leg)")
     args = ap.parse_args()
 
     import torch
@@ -329,6 +372,21 @@ def main():
                                            "(67108864-bp random genome + reverse complement), three-pass SMEM seeding"}}
             smem.update(sm_extras)
 
+    bwasw = None
+    if args.bwasw_steps > 0:
+        bw_seeds, bw_t, bw_extras = bench_bwasw(ctx, rank, dist, torch, args.bwasw_steps, not args.no_cpu_baseline)
+        v = torch.tensor([bw_seeds], dtype=torch.int64, device="cuda")
+        tm = torch.tensor([bw_t], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            bwasw = {"metric": "bwa_seed_extension_mseeds_per_s", "value": int(v[0]) / float(tm[0]) / 1e6, "unit": "Mseeds/s",
+                     "steps": args.bwasw_steps, "ms_per_step": float(tm[0]) / args.bwasw_steps * 1e3, "dtype": "int32",
+                     "config": {"workload": "2^18 seeds per GPU from 150-bp reads (2 % substitutions, 15 % with a 1-5 base indel), left + "
+                                            "right banded extension, 1/-4/-1, gaps 6+1, w 100"}}
+            bwasw.update(bw_extras)
+
     line = None
     if rank == 0:
         # dominant kernel: the fp32 sweep; HIP events on the launch stream (accg_phmm_batch_time2)
@@ -356,7 +414,7 @@ def main():
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name},
             "roofline": roof, "cpu_baseline": cpu,
             "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
-            "sw": sw, "smem": smem,
+            "sw": sw, "smem": smem, "bwasw": bwasw,
         }
     batch.close()
     ctx.close()

@@ -84,10 +84,14 @@ def test_second_band_try(ctx):
     rng = np.random.default_rng(44)
     seqs, offs, pars = [], [], []
     pos = 0
-    for k in range(64):
-        ql = int(rng.integers(200, 255)); gap = int(rng.integers(76, 100)); p = int(rng.integers(20, 60))
+    for k in range(768):
+        ql = int(rng.integers(150, 255)) if k % 3 else int(rng.integers(236, 255))
+        gap = int(rng.integers(70, 130)); p = int(rng.integers(5, 120))
         q = rng.integers(0, 4, size=ql).astype(np.uint8)
-        t = np.concatenate([q[:p], rng.integers(0, 4, size=gap).astype(np.uint8), q[p:], rng.integers(0, 4, size=20).astype(np.uint8)])
+        if k % 4 == 1:                      # a repeat-rich query keeps old rows' values alive right of the band
+            unit = rng.integers(0, 4, size=int(rng.integers(2, 9))).astype(np.uint8)
+            q = np.resize(unit, ql); q[rng.random(ql) < 0.05] = rng.integers(0, 4)
+        t = np.concatenate([q[:p], rng.integers(0, 4, size=gap).astype(np.uint8), q[p:], rng.integers(0, 4, size=int(rng.integers(20, 200))).astype(np.uint8)])
         s = np.concatenate([np.zeros(0, np.uint8), q, np.zeros(0, np.uint8), t]).astype(np.uint8)   # right side only
         seqs.append(s); offs.append(pos); pos += len(s)
         pars.append([0, 0, ql, len(t), 120, 0, k])
