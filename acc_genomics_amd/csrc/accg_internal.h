@@ -36,4 +36,15 @@ struct accg_ctx {
   void* tab_mem = nullptr;      // one allocation behind both table sets
   char name[128] = {0};
   int n_cu = 0;
+  // Independent kernels of one pass (one launch per rows-per-lane class) are spread over these streams, forked from and
+  // joined back to `stream`: queued on one stream each launch would wait for the previous one's last wavefront.
+  static constexpr int N_AUX = 4;
+  hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
 };
+
+namespace accg {
+// aux streams wait for everything queued on ctx->stream so far / ctx->stream waits for everything queued on the aux streams
+hipError_t ctx_fork(accg_ctx* c);
+hipError_t ctx_join(accg_ctx* c);
+}  // namespace accg

@@ -21,17 +21,7 @@ struct accg_bwasw_batch {
   struct Launch { int K, side; uint32_t work_off, n_work; };
   std::vector<Launch> launches;
   uint64_t cells = 0;
-  // The K classes of one side are independent kernels whose wavefronts run for hundreds of microseconds: queued on one stream
-  // every launch would wait for the previous one to drain.  They are spread over a few streams forked from / joined to the
-  // context's stream instead; the right-side pass forks after the left-side pass has joined.
-  static constexpr int N_AUX = 4;
-  hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
-  ~accg_bwasw_batch() {
-    for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) hipFree(p);
-    for (int i = 0; i < N_AUX; i++) { if (aux[i]) hipStreamDestroy(aux[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
-    if (ev_fork) hipEventDestroy(ev_fork);
-  }
+  ~accg_bwasw_batch() { for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) hipFree(p); }
 };
 
 extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const uint8_t* seqs, const uint32_t* seq_off,
@@ -98,11 +88,6 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
       b->launches.push_back(L);
     }
   }
-  for (int i = 0; i < accg_bwasw_batch::N_AUX; i++) {
-    ACCG_HIP(hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking));
-    ACCG_HIP(hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming));
-  }
-  ACCG_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
   ACCG_HIP(hipMalloc((void**)&b->d_blob, blob.size()));
   ACCG_HIP(hipMalloc((void**)&b->d_seeds, std::max<size_t>(n_seeds, 1) * sizeof(BwaswSeed)));
   ACCG_HIP(hipMalloc((void**)&b->d_work, std::max<size_t>(work.size(), 1) * sizeof(BwaswWork)));
@@ -122,20 +107,17 @@ extern "C" int accg_bwasw_batch_run(accg_bwasw_batch* b) {
   ACCG_HIP(hipSetDevice(b->ctx->device));
   BwaswArgs a;
   a.blob = b->d_blob; a.seeds = b->d_seeds; a.out = b->d_out;
-  hipStream_t main = b->ctx->stream;
+  // The K classes of one side are independent kernels whose wavefronts run for hundreds of microseconds: they are spread over
+  // the context's forked streams; the right-side pass forks after the left-side pass has joined.
   for (int side = 0; side < 2; side++) {
-    ACCG_HIP(hipEventRecord(b->ev_fork, main));
-    for (int i = 0; i < accg_bwasw_batch::N_AUX; i++) ACCG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+    ACCG_HIP(ctx_fork(b->ctx));
     int rr = 0;
     for (const auto& L : b->launches) {
       if (L.side != side) continue;
       a.work = b->d_work + L.work_off;
-      ACCG_HIP(bwasw_launch(L.K, L.side, a, L.n_work, b->aux[rr++ % accg_bwasw_batch::N_AUX]));
+      ACCG_HIP(bwasw_launch(L.K, L.side, a, L.n_work, b->ctx->aux[rr++ % accg_ctx::N_AUX]));
     }
-    for (int i = 0; i < accg_bwasw_batch::N_AUX; i++) {
-      ACCG_HIP(hipEventRecord(b->ev_join[i], b->aux[i]));
-      ACCG_HIP(hipStreamWaitEvent(main, b->ev_join[i], 0));
-    }
+    ACCG_HIP(ctx_join(b->ctx));
   }
   return ACCG_OK;
 }

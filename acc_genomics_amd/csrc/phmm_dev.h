@@ -5,7 +5,7 @@
 
 namespace accg {
 
-constexpr int PHMM_GROUPS = 4;          // reads per wavefront (read <= 255 bp; 2 for <= 511, 1 for <= 1023)
+constexpr int PHMM_GROUPS = 8;          // reads per wavefront (8 lanes per read up to 127 bp, 16 up to 255, 32 up to 511, 64 up to 1023)
 constexpr int PHMM_MAX_K = 16;          // rows per lane
 constexpr int PHMM_STREAM_MAX = 4096;   // haplotype stream entries per work item (bubbles included)
 constexpr int PHMM_HAPS_MAX = 48;       // haplotypes per work item
@@ -22,7 +22,7 @@ constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap
 }
 constexpr uint32_t PHMM_NO_READ = 0xFFFFFFFFu;
 
-// One wavefront's job: up to four reads against a list of haplotypes.
+// One wavefront's job: up to eight reads against a list of haplotypes.
 struct PhmmWork {
   uint32_t read[PHMM_GROUPS];  // global read index or PHMM_NO_READ
   uint32_t hap_off;            // first entry of this job in PhmmArgs::hap_ids
@@ -94,7 +94,8 @@ hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hi
 
 // Launchers (phmm_kernel.hip). K = rows per lane, 1..PHMM_MAX_K.
 // a.stream_cap / a.haps_cap = largest haplotype stream (entries, bubbles included) / haplotype count among the jobs of this launch.
-void phmm_pick(uint32_t read_len, int* lpp, int* K);
+constexpr int PHMM_K8_DEFAULT = 13;   // 8 lanes per read while the rows fit K <= 13 (beyond that the 2-wave occupancy costs more than it saves)
+void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);
 hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 // fp64 rescue pass: same jobs as the fp32 pass; a wavefront redoes only the haplotypes for which one of
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.

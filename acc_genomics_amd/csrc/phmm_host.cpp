@@ -55,6 +55,11 @@ extern "C" int accg_init(int device, accg_ctx** out) {
   ACCG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   ACCG_HIP(hipEventCreate(&c->ev0));
   ACCG_HIP(hipEventCreate(&c->ev1));
+  for (int i = 0; i < accg_ctx::N_AUX; i++) {
+    ACCG_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+    ACCG_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+  }
+  ACCG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   const HostTables& t = host_tables();
   const size_t nf = 128 * 3 + 8256, bytes = nf * sizeof(float) + nf * sizeof(double);
   ACCG_HIP(hipMalloc(&c->tab_mem, bytes));
@@ -77,9 +82,29 @@ extern "C" void accg_shutdown(accg_ctx* c) {
   if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  for (int i = 0; i < accg_ctx::N_AUX; i++) {
+    if (c->aux[i]) { hipStreamSynchronize(c->aux[i]); hipStreamDestroy(c->aux[i]); }
+    if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->tab_mem) hipFree(c->tab_mem);
   delete c;
 }
+namespace accg {
+hipError_t ctx_fork(accg_ctx* c) {
+  hipError_t e = hipEventRecord(c->ev_fork, c->stream);
+  for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) e = hipStreamWaitEvent(c->aux[i], c->ev_fork, 0);
+  return e;
+}
+hipError_t ctx_join(accg_ctx* c) {
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) {
+    e = hipEventRecord(c->ev_join[i], c->aux[i]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join[i], 0);
+  }
+  return e;
+}
+}  // namespace accg
 extern "C" void* accg_stream(accg_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int accg_device_name(accg_ctx* c, char* buf, size_t n) {
   if (!c || !buf || !n) return ACCG_ERR_BAD_ARG;
@@ -242,7 +267,9 @@ void partition(accg_phmm_batch& b) {
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
   // quads per region, by descending read length so that the four reads of a wavefront need the same K
-  struct Quad { uint32_t read[4]; int K, lpp; };
+  struct Quad { uint32_t read[PHMM_GROUPS]; int K, lpp; };
+  const char* e8 = getenv("ACCG_PHMM_LPP8");                 // A/B knob: largest K run with 8 lanes per read (0 = never)
+  const int max_k8 = e8 ? atoi(e8) : PHMM_K8_DEFAULT;
   std::vector<std::vector<Quad>> quads(b.regions.size());
   b.sorted_reads.assign(b.rd.size(), 0);
   b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
@@ -256,7 +283,7 @@ void partition(accg_phmm_batch& b) {
     std::copy(order.begin(), order.end(), b.sorted_reads.begin() + r.read0);
     for (uint32_t i = 0; i < r.n_reads;) {        // the longest read of a wavefront decides lanes per read and K
       Quad Q;
-      phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K);
+      phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K, max_k8);
       const uint32_t per = 64 / Q.lpp;
       for (uint32_t g = 0; g < PHMM_GROUPS; g++) Q.read[g] = (g < per && i + g < r.n_reads) ? order[i + g] : PHMM_NO_READ;
       i += per;
@@ -377,10 +404,15 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
 int launch_f32(accg_phmm_batch* b, int mode) {
   ACCG_HIP(hipMemsetAsync(b->d_state.p, 0, state_words(*b) * sizeof(uint32_t), b->ctx->stream));   // flags, counts, n_rescued
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
+  const bool fork = b->launches.size() > 1;          // several rows-per-lane classes: run them side by side
+  if (fork) ACCG_HIP(ctx_fork(b->ctx));
+  int rr = 0;
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, b->ctx->stream));
+    hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : b->ctx->stream;
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, st));
   }
+  if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
 }
 int launch_rescue(accg_phmm_batch* b, int mode) {
@@ -394,12 +426,19 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   a.work = b->d_rescue_jobs.p;
   a.stream_cap = b->rescue_stream_cap; a.haps_cap = b->rescue_haps_cap;
   static const int cls_lpp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 32, 64}, cls_k[PHMM_RESCUE_CLASSES] = {4, 8, 12, 16, 16, 16};
+  int n_cls = 0;
+  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) n_cls += b->rescue_bound[c] != 0;
+  const bool fork = n_cls > 1;
+  if (fork) ACCG_HIP(ctx_fork(b->ctx));
+  int rr = 0;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
     const uint32_t bound = std::min(b->rescue_bound[c], b->rescue_cap);
     if (!bound) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
-    ACCG_HIP(phmm_launch_rescue_f64(cls_k[c], cls_lpp[c], mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, s));
+    hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
+    ACCG_HIP(phmm_launch_rescue_f64(cls_k[c], cls_lpp[c], mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, st));
   }
+  if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
 }
 

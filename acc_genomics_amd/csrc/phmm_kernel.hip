@@ -9,7 +9,8 @@
 //     result  = sum_c (M[R][c] + X[R][c]),   Y[0][c] = INIT/H, everything else on the border 0.
 //
 // How it is mapped (a design of its own, neither the FPGA PE array nor the AVX stripes):
-//   * one wavefront = four reads (reads > 255 bp: two reads on 32 lanes each, > 511 bp: one read on all 64);
+//   * one wavefront = four reads of 16 lanes (reads <= 127 bp: eight reads of 8 lanes; > 255 bp: two reads on 32 lanes
+//     each, > 511 bp: one read on all 64);
 //     read g lives in DPP row g (16 lanes); lane l of the row owns K
 //     consecutive read rows in registers (K = ceil((R+1)/16) is a template parameter, so all row
 //     state is register-resident and indexed at compile time).  Rows are right-aligned: the last
@@ -43,9 +44,11 @@ __device__ __forceinline__ int char_index(uint8_t b) {   // bases are validated 
 // lane l <- lane l-1 inside a group of LPP lanes; the first lane of a group receives 0.
 // LPP = 16: DPP row_shr:1.  LPP = 32 / 64: wave_shr:1 (lane 32's source is lane 31, the last lane of the
 // other group, whose a_out / x_out are 0 by construction when LPP = 32 - see the lane-constant setup).
+// LPP = 8: row_shr:1 again; lane 8's source is lane 7, the last lane of the other group of the row, which hands
+// over zeros for the same reason.
 template <int LPP>
 __device__ __forceinline__ int shr1_bits(int v) {
-  return LPP == 16 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
+  return LPP <= 16 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
 }
 template <int LPP>
 __device__ __forceinline__ float group_shr1(float v) { return __builtin_bit_cast(float, shr1_bits<LPP>(__builtin_bit_cast(int, v))); }
@@ -127,7 +130,7 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
   s.x_out = mul_add2<STRICT>(s.M[K - 1], s.nMX, s.X[K - 1], s.nXX);
   // last lane of a group: M + X of the last read row (baseline_impl.cpp:91).  With one or four groups per wave it is
   // x_out itself (nMX = nXX = 1, nobody consumes it); with two groups lane 31's x_out must stay 0 for lane 32.
-  s.acc = s.acc + (LPP == 32 ? s.M[K - 1] + s.X[K - 1] : s.x_out);
+  s.acc = s.acc + ((LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out);
 }
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       s.nGM = a.tab.omph[qc];
       s.nMX = a.tab.ph[qi];
       s.nXX = a.tab.ph[qc];
-    } else if (l == LPP - 1 && LPP != 32) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
+    } else if (l == LPP - 1 && LPP != 32 && LPP != 8) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
     else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
   if (!STRICT) {
@@ -327,7 +330,15 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
     const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL);             \
     hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE>), grid, block, lds, st, a, work_base);         \
   } break;
-  if (lpp == 16) {
+  if (lpp == 8) {      // not for the rescue pass, whose jobs are planned on the device in 16/32/64-lane classes
+    if constexpr (!RESCUE) {
+      switch (K) {
+        ACCG_CASE(1, 8) ACCG_CASE(2, 8) ACCG_CASE(3, 8) ACCG_CASE(4, 8) ACCG_CASE(5, 8) ACCG_CASE(6, 8) ACCG_CASE(7, 8) ACCG_CASE(8, 8)
+        ACCG_CASE(9, 8) ACCG_CASE(10, 8) ACCG_CASE(11, 8) ACCG_CASE(12, 8) ACCG_CASE(13, 8) ACCG_CASE(14, 8) ACCG_CASE(15, 8) ACCG_CASE(16, 8)
+        default: return hipErrorInvalidValue;
+      }
+    } else return hipErrorInvalidValue;
+  } else if (lpp == 16) {
     switch (K) {
       ACCG_CASE(1, 16) ACCG_CASE(2, 16) ACCG_CASE(3, 16) ACCG_CASE(4, 16) ACCG_CASE(5, 16) ACCG_CASE(6, 16) ACCG_CASE(7, 16) ACCG_CASE(8, 16)
       ACCG_CASE(9, 16) ACCG_CASE(10, 16) ACCG_CASE(11, 16) ACCG_CASE(12, 16) ACCG_CASE(13, 16) ACCG_CASE(14, 16) ACCG_CASE(15, 16) ACCG_CASE(16, 16)
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
     const uint32_t base = s_cnt;
     for (uint32_t c = tid; c < R.n_chunks; c += 256) {
       PhmmWork w;
-      for (uint32_t g = 0; g < 4; g++) w.read[g] = (g < per && i + g < nf) ? out[i + g] : PHMM_NO_READ;
+      for (uint32_t g = 0; g < PHMM_GROUPS; g++) w.read[g] = (g < per && i + g < nf) ? out[i + g] : PHMM_NO_READ;
       w.hap_off = p.chunks[R.chunk0 + c].ids0; w.n_haps = p.chunks[R.chunk0 + c].n; w.pad_[0] = w.pad_[1] = 0;
       if (base + c < p.cap) p.jobs[(size_t)cls * p.cap + base + c] = w;
     }
@@ -411,8 +422,11 @@ hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, const PhmmArgs<do
 }
 
 // (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support
-void phmm_pick(uint32_t len, int* lpp, int* K) {
+void phmm_pick(uint32_t len, int* lpp, int* K, int max_k8) {
   const uint32_t rows = len + 1;            // one row reserved as "row 0"
+  // 8 lanes per read: twice the rows per lane, so the per-step overhead (hand-off, stream and table reads) is spread
+  // over twice the cells, and the padding to a multiple of the lane count halves
+  if (rows <= 8u * (uint32_t)(max_k8 < PHMM_MAX_K ? max_k8 : PHMM_MAX_K)) { *lpp = 8; *K = (int)((rows + 7) / 8); return; }
   if (rows <= 256) { *lpp = 16; *K = (int)((rows + 15) / 16); return; }
   static const int ks[] = {9, 10, 12, 14, 16};
   for (int l : {32, 64}) {

@@ -11,12 +11,14 @@ from acc_genomics_amd import synth
 import orc
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+NFRAC = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
+RLEN = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (70, 152)
 rng = synth.rng_for(3)
 t0 = time.time()
 regs = []
 for _ in range(R):
-    rl = int(rng.integers(70, 152)); hl = int(rng.integers(max(70, rl), 501))   # lengths uniform per region
-    regs.append(synth.make_region(rng, 128, 16, rl, hl, n_frac=0.01, unrelated_frac=0.10))
+    rl = int(rng.integers(RLEN[0], RLEN[1])); hl = int(rng.integers(max(70, rl), 501))   # lengths uniform per region
+    regs.append(synth.make_region(rng, 128, 16, rl, hl, n_frac=NFRAC, unrelated_frac=0.10))
 ser = [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]
 print("generated %d regions in %.1f s" % (R, time.time() - t0))
 with A.Context(0) as ctx:
