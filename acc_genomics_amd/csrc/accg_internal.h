@@ -25,6 +25,11 @@ struct HostTables {
 };
 const HostTables& host_tables();
 
+// Threads for the host-side post-processing loops: the CPUs this process may really use (cgroup quota when there is one,
+// else the affinity mask), ACCG_HOST_THREADS overrides.  OpenMP's default is every CPU it can see, which under a quota
+// just gets the process throttled.
+int host_threads();
+
 }  // namespace accg
 
 struct accg_ctx {

@@ -4,6 +4,8 @@
 // FalconPairHMM::computePairhmmAVX (pairhmm/xlnx/host/FalconPairHMM.cpp:69-95).
 #include <math.h>
 #include <stdlib.h>
+#include <sched.h>
+#include <stdio.h>
 #include <string.h>
 #include <algorithm>
 #include <functional>
@@ -91,6 +93,21 @@ extern "C" void accg_shutdown(accg_ctx* c) {
   delete c;
 }
 namespace accg {
+int host_threads() {
+  static const int n = [] {
+    if (const char* e = getenv("ACCG_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    int cpus = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32]; long per = 0;
+      if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) cpus = std::max(1, std::min(cpus, (int)(atol(q) / per)));
+      fclose(f);
+    }
+    return std::min(cpus, 64);
+  }();
+  return n;
+}
 hipError_t ctx_fork(accg_ctx* c) {
   hipError_t e = hipEventRecord(c->ev_fork, c->stream);
   for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) e = hipStreamWaitEvent(c->aux[i], c->ev_fork, 0);
@@ -590,7 +607,7 @@ extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, doubl
     if (nresc) { r64.resize(b->pairs); ACCG_HIP(hipMemcpy(r64.data(), b->d_out64.p, b->pairs * sizeof(double), hipMemcpyDeviceToHost)); }
     const HostTables& t = host_tables();
     // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads())
     for (int64_t i = 0; i < (int64_t)b->pairs; i++) {
       if (raw[i] < PHMM_MIN_ACCEPTED) out_log10[i] = log10(r64[i]) - t.log10_init_d;
       else out_log10[i] = (double)(log10f(raw[i]) - t.log10_init_f);

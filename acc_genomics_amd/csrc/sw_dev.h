@@ -25,7 +25,10 @@ struct SwArgs {
   uint64_t bt_item_stride;   // uint4 elements per wavefront job
   int32_t* cig_n;            // per pair: number of elements, or -(needed) when max_el was too small, or -1 (no alignment)
   int32_t* cig_off;          // per pair: alignment_offset
-  int32_t* cig_el;           // per pair: max_el x {length, state}
+  int32_t* cig_el;           // per pair: max_el x {length, state} (device-side slots, backtrace order)
+  int32_t* cig_packed;       // all CIGARs back to back in alignment order: pair k's elements start at cig_start[k]
+  unsigned long long* cig_start;
+  unsigned long long* cig_total;   // elements allocated so far (one wave-aggregated atomic per wavefront)
   int32_t max_el;
 };
 

@@ -32,12 +32,16 @@ struct accg_sw_batch {
   SwArgs args{};
   // backtrace mode
   uint4* d_bt = nullptr; uint64_t bt_bytes = 0;
-  int32_t *d_cig_n = nullptr, *d_cig_off = nullptr, *d_cig_el = nullptr;
+  int32_t *d_cig_n = nullptr, *d_cig_off = nullptr, *d_cig_el = nullptr, *d_cig_packed = nullptr;
+  unsigned long long *d_cig_start = nullptr, *d_cig_total = nullptr;
+  int32_t* h_packed = nullptr; uint64_t h_packed_cap = 0;   // pinned staging for the slot-form readback
   int max_el = 0;
   ~accg_sw_batch() {            // also reached on the error paths of accg_sw_batch_create
     for (void* p : {(void*)d_refs, (void*)d_alts, (void*)d_strat, (void*)d_rl, (void*)d_al, (void*)d_score, (void*)d_p1, (void*)d_p2,
-                    (void*)d_work, (void*)d_bt, (void*)d_cig_n, (void*)d_cig_off, (void*)d_cig_el})
+                    (void*)d_work, (void*)d_bt, (void*)d_cig_n, (void*)d_cig_off, (void*)d_cig_el, (void*)d_cig_packed,
+                    (void*)d_cig_start, (void*)d_cig_total})
       if (p) hipFree(p);
+    if (h_packed) hipHostFree(h_packed);
   }
 };
 
@@ -153,7 +157,11 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   if (max_el != b->max_el) {
     ACCG_HIP(hipStreamSynchronize(s));
     if (b->d_cig_el) { hipFree(b->d_cig_el); b->d_cig_el = nullptr; }
+    if (b->d_cig_packed) { hipFree(b->d_cig_packed); b->d_cig_packed = nullptr; }
     ACCG_HIP(hipMalloc((void**)&b->d_cig_el, n1 * max_el * 2 * sizeof(int32_t)));
+    ACCG_HIP(hipMalloc((void**)&b->d_cig_packed, n1 * max_el * 2 * sizeof(int32_t)));
+    if (!b->d_cig_start) ACCG_HIP(hipMalloc((void**)&b->d_cig_start, n1 * sizeof(unsigned long long)));
+    if (!b->d_cig_total) ACCG_HIP(hipMalloc((void**)&b->d_cig_total, sizeof(unsigned long long)));
     if (!b->d_cig_n) ACCG_HIP(hipMalloc((void**)&b->d_cig_n, n1 * sizeof(int32_t)));
     if (!b->d_cig_off) ACCG_HIP(hipMalloc((void**)&b->d_cig_off, n1 * sizeof(int32_t)));
     b->max_el = max_el;
@@ -176,6 +184,8 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   }
   SwArgs a = b->args;
   a.bt = b->d_bt; a.cig_n = b->d_cig_n; a.cig_off = b->d_cig_off; a.cig_el = b->d_cig_el; a.max_el = max_el;
+  a.cig_packed = b->d_cig_packed; a.cig_start = b->d_cig_start; a.cig_total = b->d_cig_total;
+  ACCG_HIP(hipMemsetAsync(b->d_cig_total, 0, sizeof(unsigned long long), s));
   for (const SwLaunch& l : b->launches) {
     a.bt_item_stride = sw_bt_item_uint4(l.sweep_cap, l.lpp);
     const uint64_t per = a.bt_item_stride * sizeof(uint4);
@@ -189,16 +199,52 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   return ACCG_OK;
 }
 
-extern "C" int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* offsets, int32_t* elements) {
+// The CIGARs leave the device packed back to back (a few elements per pair); the fixed-slot layout of the reference's
+// Cigar arrays is rebuilt on the host.
+extern "C" int accg_sw_batch_cigars_packed(accg_sw_batch* b, int32_t* n_el, int32_t* offsets, uint64_t* starts, int32_t* elements,
+                                           uint64_t capacity, uint64_t* total) {
   if (!b || !b->d_cig_n) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   const size_t n = (size_t)b->n;
+  unsigned long long tot = 0;
+  ACCG_HIP(hipMemcpy(&tot, b->d_cig_total, sizeof tot, hipMemcpyDeviceToHost));
+  if (total) *total = tot;
   if (n) {
     if (n_el) ACCG_HIP(hipMemcpy(n_el, b->d_cig_n, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (offsets) ACCG_HIP(hipMemcpy(offsets, b->d_cig_off, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (elements) ACCG_HIP(hipMemcpy(elements, b->d_cig_el, n * b->max_el * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (starts) ACCG_HIP(hipMemcpy(starts, b->d_cig_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
+  if (elements) {
+    if (capacity < tot) return ACCG_ERR_BAD_ARG;      // *total says how much is needed
+    if (tot) ACCG_HIP(hipMemcpy(elements, b->d_cig_packed, tot * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return ACCG_OK;
+}
+
+extern "C" int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* offsets, int32_t* elements) {
+  if (!b || !b->d_cig_n) return ACCG_ERR_BAD_ARG;
+  const size_t n = (size_t)b->n;
+  if (!elements) return accg_sw_batch_cigars_packed(b, n_el, offsets, nullptr, nullptr, 0, nullptr);
+  std::vector<int32_t> cnt(n);
+  std::vector<uint64_t> starts(n);
+  uint64_t tot = 0;
+  int st = accg_sw_batch_cigars_packed(b, cnt.data(), offsets, starts.data(), nullptr, 0, &tot);
+  if (st != ACCG_OK) return st;
+  if (tot > b->h_packed_cap) {
+    if (b->h_packed) hipHostFree(b->h_packed);
+    b->h_packed = nullptr; b->h_packed_cap = 0;
+    ACCG_HIP(hipHostMalloc((void**)&b->h_packed, tot * 2 * sizeof(int32_t), hipHostMallocDefault));
+    b->h_packed_cap = tot;
+  }
+  const int32_t* packed = b->h_packed;
+  st = accg_sw_batch_cigars_packed(b, nullptr, nullptr, nullptr, b->h_packed, tot, nullptr);
+  if (st != ACCG_OK) return st;
+  const size_t slot = (size_t)b->max_el * 2;
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads())
+  for (size_t k = 0; k < n; k++)
+    if (cnt[k] > 0) memcpy(elements + k * slot, packed + starts[k] * 2, (size_t)cnt[k] * 2 * sizeof(int32_t));
+  if (n_el) memcpy(n_el, cnt.data(), n * sizeof(int32_t));
   return ACCG_OK;
 }
 

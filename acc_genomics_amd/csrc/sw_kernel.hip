@@ -305,10 +305,12 @@ template <bool LANE_IS_ALT>
 __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t wi = tid >> 3, slot = tid & 7;
-  if (wi >= n_work) return;
-  const uint32_t pair = a.work[work_base + wi].pair[slot];
+  const uint32_t pair = wi < n_work ? a.work[work_base + wi].pair[slot] : SW_NO_PAIR;
   const int g = slot >> 1, half = slot & 1;
-  if (pair == SW_NO_PAIR || (!p16 && half) || g >= 64 / LPP) return;
+  const bool live = !(pair == SW_NO_PAIR || (!p16 && half) || g >= 64 / LPP);
+  int n = 0;
+  int32_t* el = nullptr;
+  if (live) {
   const int refLen = a.ref_len[pair], altLen = a.alt_len[pair], strat = a.strategy[pair];
   const int nl = LANE_IS_ALT ? altLen : refLen;
   const int pad = LPP * K - nl;
@@ -323,9 +325,8 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   // planes: 0 lane-direction gap opened, 1 sweep-direction gap opened; "right" (insertion) runs along the alternate
   const int P_HOPEN = LANE_IS_ALT ? 0 : 1, P_VOPEN = LANE_IS_ALT ? 1 : 0;
   int p1 = a.p1[pair], p2 = a.p2[pair];
-  int32_t* el = a.cig_el + (size_t)pair * a.max_el * 2;
+  el = a.cig_el + (size_t)pair * a.max_el * 2;
   const int cap = a.max_el;
-  int n = 0;
   auto push = [&](int len, int st) {           // addCigarElement (sw_host.cpp:17-26): non-positive lengths are dropped
     if (len <= 0) return;
     if (n < cap) { el[2 * n] = len; el[2 * n + 1] = st; }
@@ -358,14 +359,27 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   else if (strat == 3) { push(seg + p2, state); off = p1 - p2; }                      // :2386-2389
   else { push(seg, state); if (p1 > 0) push(p1, 2); else if (p2 > 0) push(p2, 1); off = 0; }   // :2390-2400
   a.cig_off[pair] = off;
-  if (n <= 0) { a.cig_n[pair] = -1; return; }
-  if (n > cap) { a.cig_n[pair] = -n; return; }
-  for (int x = 0, y = n - 1; x < y; x++, y--) {                                       // :2408-2417
-    int t0 = el[2 * x], t1 = el[2 * x + 1];
-    el[2 * x] = el[2 * y]; el[2 * x + 1] = el[2 * y + 1];
-    el[2 * y] = t0; el[2 * y + 1] = t1;
+  if (n <= 0) { a.cig_n[pair] = -1; n = 0; }
+  else if (n > cap) { a.cig_n[pair] = -n; n = 0; }
+  else a.cig_n[pair] = n;
   }
-  a.cig_n[pair] = n;
+  // Space in the packed result: one atomic per wavefront, lanes take consecutive ranges; the copy reverses the list
+  // (the walk produced it from the end cell backwards, calculateCigarOneBatch reverses it at :2408-2417).
+  const int lane = threadIdx.x & 63;
+  int incl = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;
+  unsigned long long base = 0;
+  if (lane == 63) base = atomicAdd(a.cig_total, (unsigned long long)total);
+  base = __shfl(base, 63);
+  if (!live) return;
+  const unsigned long long start = base + (unsigned long long)(incl - n);
+  a.cig_start[pair] = start;
+  int2* dst = reinterpret_cast<int2*>(a.cig_packed) + start;
+  const int2* src = reinterpret_cast<const int2*>(el);
+  for (int x = 0; x < n; x++) dst[x] = src[n - 1 - x];
 }
 
 template <int LPP, bool P16, bool LIA, bool BT>

@@ -68,6 +68,7 @@ def load():
     L.accg_sw_batch_destroy.argtypes = [vp]
     L.accg_sw_batch_run_cigar.argtypes = [vp, C.c_int]
     L.accg_sw_batch_cigars.argtypes = [vp, vp, vp, vp]
+    L.accg_sw_batch_cigars_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp]
     L.accg_smem_index_create.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(vp)]
     L.accg_smem_index_destroy.argtypes = [vp]
     L.accg_smem_batch_create.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
@@ -233,6 +234,16 @@ class SwBatch:
         el = np.zeros((self.n, self.max_el, 2), np.int32)
         _check(self.L.accg_sw_batch_cigars(self.h, n_el.ctypes.data, off.ctypes.data, el.ctypes.data))
         return n_el, off, el
+
+    def cigars_packed(self):
+        """-> (n_el int32[n], alignment_offset int32[n], starts uint64[n], elements int32[total, 2]): CIGARs back to back."""
+        n_el, off = np.zeros(self.n, np.int32), np.zeros(self.n, np.int32)
+        starts = np.zeros(self.n, np.uint64)
+        total = C.c_uint64()
+        _check(self.L.accg_sw_batch_cigars_packed(self.h, n_el.ctypes.data, off.ctypes.data, starts.ctypes.data, None, 0, C.byref(total)))
+        el = np.zeros((total.value, 2), np.int32)
+        _check(self.L.accg_sw_batch_cigars_packed(self.h, None, None, None, el.ctypes.data, total.value, None))
+        return n_el, off, starts, el
 
     def close(self):
         if self.h:

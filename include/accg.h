@@ -127,6 +127,10 @@ int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el);
 /* n_el[k] > 0: element count; -1: calculateCigarOneBatch's "no element" failure (:2404-2407);
  * < -1: -(elements needed) > max_el, rerun with a larger max_el.  elements: int32[n][max_el][2]. */
 int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* alignment_offsets, int32_t* elements);
+/* The same results as the device holds them: all CIGARs back to back, pair k's n_el[k] elements at elements[2 * starts[k]].
+ * *total = elements in all; elements (capacity in elements) may be NULL to query it.  Any pointer may be NULL. */
+int accg_sw_batch_cigars_packed(accg_sw_batch* b, int32_t* n_el, int32_t* alignment_offsets, uint64_t* starts, int32_t* elements,
+                                uint64_t capacity, uint64_t* total);
 void accg_sw_batch_destroy(accg_sw_batch* b);
 
 /* ---- SMEM seeding (BWA-MEM, configs[4]) -----------------------------------------------------------------

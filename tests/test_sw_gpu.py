@@ -249,3 +249,27 @@ def test_full_size_c2_cigar_properties(ctx):
         wn, woff, wcig = _oracle_cigar(refs[k].tobytes(), alts[k].tobytes(), 0)
         assert (n_el[k], off[k]) == (wn, woff)
         assert list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig
+
+
+def test_packed_cigars_agree_with_slots(ctx):
+    """accg_sw_batch_cigars_packed: the same CIGARs back to back; ranges are disjoint and cover [0, total)."""
+    rng = synth.rng_for(530)
+    n = 3000
+    refs, rl, alts, al = _ragged(rng, n, 20, 200, 20, 200)
+    strat = rng.integers(0, 4, size=n).astype(np.uint8)
+    with A.SwBatch(ctx, refs, rl, alts, al, strategies=strat) as b:
+        b.run_cigar(128)
+        n_el, off, el = b.cigars()
+        pn, poff, starts, pel = b.cigars_packed()
+        b.run_cigar(128)                                   # a second run starts from an empty packed buffer again
+        pn2, _, starts2, pel2 = b.cigars_packed()
+    assert np.array_equal(pn, n_el) and np.array_equal(poff, off) and np.array_equal(pn2, n_el)
+    cnt = np.maximum(pn, 0)
+    assert len(pel) == int(cnt.sum()) == len(pel2)
+    order = np.argsort(starts[cnt > 0])
+    s, c = starts[cnt > 0][order].astype(np.int64), cnt[cnt > 0][order]
+    assert s[0] == 0 and np.array_equal(s[1:], (s + c)[:-1])
+    for k in range(n):
+        if pn[k] > 0:
+            assert np.array_equal(pel[int(starts[k]):int(starts[k]) + pn[k]], el[k, :pn[k]]), k
+            assert np.array_equal(pel2[int(starts2[k]):int(starts2[k]) + pn[k]], el[k, :pn[k]]), k

@@ -18,3 +18,4 @@ with A.Context(0) as ctx:
             print("run_cigar %.2f ms" % ((t1 - t0) * 1e3))
         t0 = time.perf_counter(); n_el, off, el = b.cigars(); print("D2H cigars %.2f ms" % ((time.perf_counter() - t0) * 1e3))
         print("mean elements", n_el.mean(), "max", n_el.max())
+        t0 = time.perf_counter(); pn, poff, starts, pel = b.cigars_packed(); print("D2H packed cigars %.2f ms (%d elements)" % ((time.perf_counter() - t0) * 1e3, len(pel)))
