@@ -16,10 +16,14 @@ for f in glob.glob(os.path.join(root, "pmc_%s_*" % tag, "*", "*counter_collectio
             k = "phmm_f32"
         elif "phmm_kernel<double" in name:
             k = "phmm_rescue_f64"
+        elif "bwasw_kernel" in name:
+            k = "bwasw"
         elif "sw_trace_kernel" in name:
             k = "sw_trace"
         elif "sw_kernel" in name:
             k = "sw_fill_bt" if name.split(">(")[0].rstrip().endswith("true") else "sw"
+        elif "smem_kernel" in name:
+            k = "smem"
         else:
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
