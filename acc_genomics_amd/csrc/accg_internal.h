@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/accg.h"
 #include "phmm_dev.h"
@@ -25,6 +28,20 @@ struct HostTables {
 };
 const HostTables& host_tables();
 
+// Device memory cache of a context.  The one-shot entry points (accg_phmm_region = one call per active region of the caller)
+// build and drop a whole batch per call; hipMalloc/hipFree of its ~17 buffers cost more than the kernels of a small region.
+// Blocks are reused in stream order (everything runs on ctx->stream or on streams joined back to it), so a block handed out
+// again is only touched after the work that used it before.  Large blocks (> 256 MiB) bypass the cache.
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_;
+  std::unordered_map<void*, size_t> live_;
+  size_t cached = 0;
+  hipError_t get(size_t bytes, void** p);
+  void put(void* p);
+  void drain();
+};
+
 // Threads for the host-side post-processing loops: the CPUs this process may really use (cgroup quota when there is one,
 // else the affinity mask), ACCG_HOST_THREADS overrides.  OpenMP's default is every CPU it can see, which under a quota
 // just gets the process throttled.
@@ -41,6 +58,11 @@ struct accg_ctx {
   void* tab_mem = nullptr;      // one allocation behind both table sets
   char name[128] = {0};
   int n_cu = 0;
+  accg::DevPool pool;
+  // pinned host staging (grown on demand): one H2D per batch_create, one D2H per results call.  A context is driven by one
+  // host thread at a time (it owns one stream), so the staging needs no lock.
+  void* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
   // Independent kernels of one pass (one launch per rows-per-lane class) are spread over these streams, forked from and
   // joined back to `stream`: queued on one stream each launch would wait for the previous one's last wavefront.
   static constexpr int N_AUX = 4;
@@ -51,5 +73,6 @@ struct accg_ctx {
 namespace accg {
 // aux streams wait for everything queued on ctx->stream so far / ctx->stream waits for everything queued on the aux streams
 hipError_t ctx_fork(accg_ctx* c);
+hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p);   // pinned staging of at least `bytes`
 hipError_t ctx_join(accg_ctx* c);
 }  // namespace accg

@@ -8,7 +8,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <functional>
+#include <map>
 #include <memory>
 #include <numeric>
 #include "accg_internal.h"
@@ -89,10 +91,57 @@ extern "C" void accg_shutdown(accg_ctx* c) {
     if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  c->pool.drain();
+  if (c->h_stage) hipHostFree(c->h_stage);
   if (c->tab_mem) hipFree(c->tab_mem);
   delete c;
 }
 namespace accg {
+namespace {
+constexpr size_t POOL_MAX_BLOCK = 256ull << 20, POOL_MAX_CACHED = 4ull << 30;
+size_t pool_round(size_t b) {
+  if (b <= 256) return 256;
+  if (b <= (1u << 20)) { size_t r = 256; while (r < b) r <<= 1; return r; }
+  return (b + (1u << 20) - 1) >> 20 << 20;
+}
+}  // namespace
+hipError_t DevPool::get(size_t bytes, void** p) {
+  const size_t cap = pool_round(bytes);
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = free_.lower_bound(cap);
+    if (it != free_.end() && it->first <= cap * 2) {
+      *p = it->second; live_[*p] = it->first; cached -= it->first; free_.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, cap);
+  if (e != hipSuccess) {               // give the cache back to the driver and try once more
+    drain();
+    e = hipMalloc(p, cap);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> g(mu);
+  live_[*p] = cap;
+  return hipSuccess;
+}
+void DevPool::put(void* p) {
+  if (!p) return;
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    cap = it->second; live_.erase(it);
+    if (cap <= POOL_MAX_BLOCK && cached + cap <= POOL_MAX_CACHED) { free_.emplace(cap, p); cached += cap; return; }
+  }
+  hipFree(p);
+}
+void DevPool::drain() {
+  std::multimap<size_t, void*> f;
+  { std::lock_guard<std::mutex> g(mu); f.swap(free_); cached = 0; }
+  for (auto& kv : f) hipFree(kv.second);
+}
 int host_threads() {
   static const int n = [] {
     if (const char* e = getenv("ACCG_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
@@ -107,6 +156,18 @@ int host_threads() {
     return std::min(cpus, 64);
   }();
   return n;
+}
+hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p) {
+  if (bytes > c->h_stage_bytes) {
+    if (c->h_stage) hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_bytes = 0;
+    const size_t cap = std::max<size_t>((bytes + (1u << 20) - 1) >> 20 << 20, 1u << 20);
+    hipError_t e = hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    c->h_stage_bytes = cap;
+  }
+  *p = c->h_stage;
+  return hipSuccess;
 }
 hipError_t ctx_fork(accg_ctx* c) {
   hipError_t e = hipEventRecord(c->ev_fork, c->stream);
@@ -147,14 +208,22 @@ namespace {
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
 struct KLaunch { int K, lpp; uint32_t work0, n_work; int stream_cap, haps_cap; };
 
+thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
+struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  DevPool* pool = nullptr;
+  bool view = false;             // points into the batch's arena; nothing to free
+  void place(void* base, size_t byte_off, size_t count) { p = (T*)((uint8_t*)base + byte_off); n = count; view = true; }
   int alloc(size_t count) {
     n = count;
     if (count == 0) return ACCG_OK;
-    ACCG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    pool = tls_pool;
+    if (pool) ACCG_HIP(pool->get(count * sizeof(T), (void**)&p));
+    else ACCG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
     return ACCG_OK;
   }
   int upload(const std::vector<T>& v, hipStream_t s) {
@@ -163,7 +232,7 @@ struct DevBuf {
     ACCG_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return ACCG_OK;
   }
-  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+  void release() { if (p && !view) { if (pool) pool->put(p); else hipFree(p); } p = nullptr; n = 0; }
   ~DevBuf() { release(); }      // error paths of batch_create free what was allocated so far
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
@@ -183,6 +252,8 @@ struct accg_phmm_batch {
   std::vector<KLaunch> launches;
   uint64_t pairs = 0, cells = 0, algo_bytes = 0;
   bool has_n = false;          // some haplotype contains an 'N': the dist table needs its fifth slab
+  DevBuf<uint8_t> d_arena;       // one allocation behind every buffer below
+  size_t res_off = 0;            // arena offset of the results block [n_rescued u64][out f32 x (pairs+1)]
   DevBuf<uint8_t> d_rblob, d_hblob;
   DevBuf<SeqRef> d_rd, d_hp;
   DevBuf<uint32_t> d_rd_out, d_hp_local, d_hap_ids;
@@ -326,31 +397,56 @@ void partition(accg_phmm_batch& b) {
   const double prologue_steps = 30.0;   // table lookups + dist table + stream build, in units of one sweep step
   uint64_t best_budget = cand[0];
   double best_span = -1;
-  std::vector<double> costs;
+  // Jobs take few distinct costs (chunk length x rows per lane), so the longest-first list schedule is simulated on
+  // histograms: job costs in descending order, slot loads as load -> number of slots.  Assigning k equal jobs to the k
+  // least-loaded slots of one bucket is what the sequential rule does one job at a time.
+  std::map<double, uint64_t, std::greater<double>> hist;
+  std::map<double, uint64_t> loads;
+  std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
+  uint64_t seen_sig = 0;
   for (uint64_t budget : cand) {
-    costs.clear();
+    hist.clear();
     uint32_t cap = 0;
+    uint64_t n_jobs = 0, sig = 1469598103934665603ull;
     for (size_t ri = 0; ri < b.regions.size(); ri++) {
       if (quads[ri].empty()) continue;
-      std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
+      runs.clear(); lens.clear();
       chunk_region(b, b.regions[ri], budget, runs, lens);
-      for (uint32_t len : lens) cap = std::max(cap, len);
-      for (const Quad& Q : quads[ri])
-        for (uint32_t len : lens) costs.push_back((len + 15 + prologue_steps) * (8.0 * Q.K + 10.0));
+      for (uint32_t len : lens) { cap = std::max(cap, len); sig = (sig ^ len) * 1099511628211ull; }
+      sig = (sig ^ 0xFFFFFFFFull) * 1099511628211ull;
+      int lastK = -1; uint64_t mult = 0;                       // quads are sorted by length: equal K come in runs
+      auto flush = [&]() { if (mult) for (uint32_t len : lens) hist[(len + 15 + prologue_steps) * (8.0 * lastK + 10.0)] += mult; };
+      for (const Quad& Q : quads[ri]) {
+        if (Q.K != lastK) { flush(); lastK = Q.K; mult = 0; }
+        mult++;
+      }
+      flush();
+      n_jobs += (uint64_t)quads[ri].size() * lens.size();
     }
-    if (costs.empty()) break;
+    if (n_jobs == 0) break;
+    if (sig == seen_sig) continue;                             // same chunking as the previous candidate
+    seen_sig = sig;
     const int slots = n_cu * waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), PHMM_HAPS_MAX);
-    std::sort(costs.begin(), costs.end(), std::greater<double>());
-    std::vector<double> heap((size_t)slots, 0.0);          // min-heap of slot loads
-    auto cmp = std::greater<double>();
-    for (double c : costs) { std::pop_heap(heap.begin(), heap.end(), cmp); heap.back() += c; std::push_heap(heap.begin(), heap.end(), cmp); }
-    double span = *std::max_element(heap.begin(), heap.end());
+    loads.clear();
+    loads[0.0] = (uint64_t)slots;
+    for (const auto& hc : hist) {
+      uint64_t left = hc.second;
+      while (left) {
+        auto lo = loads.begin();
+        const uint64_t k = std::min(left, lo->second);
+        const double nl = lo->first + hc.first;
+        if (k == lo->second) loads.erase(lo); else lo->second -= k;
+        loads[nl] += k;
+        left -= k;
+      }
+    }
+    double span = loads.rbegin()->first;
     // more resident waves per SIMD issue VALU work faster (tools/ubench.hip: 1.35 / 1.25 / 1.16 ns per instruction at 2 / 3 / 4)
     const int wpc = slots / n_cu;
     span *= wpc >= 16 ? 1.0 : wpc >= 12 ? 1.08 : wpc >= 8 ? 1.16 : 1.4;
     // the hardware dispatcher is not an ideal list scheduler: with about one job per slot it measured ~6 % behind
     // two or four per slot on configs[1] (gpurun sweep)
-    span *= 1.0 + 0.10 * (double)slots / (double)costs.size();
+    span *= 1.0 + 0.10 * (double)slots / (double)n_jobs;
     if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
   }
 
@@ -468,6 +564,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   if (!out || n_regions < 0 || (n_regions > 0 && (!reads_ser || !reads_bytes || !haps_ser || !haps_bytes))) return ACCG_ERR_BAD_ARG;
   *out = nullptr;
   ACCG_HIP(hipSetDevice(ctx->device));
+  PoolScope pool_scope(&ctx->pool);
   std::unique_ptr<accg_phmm_batch> b(new accg_phmm_batch);
   b->ctx = ctx;
   uint64_t roff = 0, hoff = 0;
@@ -497,36 +594,62 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     roff += reads_bytes[i]; hoff += haps_bytes[i];
   }
   b->algo_bytes = roff + hoff + 4 * b->pairs;   // blobs in, one float per pair out
+  const auto tp0 = std::chrono::steady_clock::now();
   partition(*b);
+  const auto tp1 = std::chrono::steady_clock::now();
   hipStream_t s = ctx->stream;
   int st;
-  if ((st = b->d_rblob.alloc(roff + 16)) != ACCG_OK) return st;
-  if ((st = b->d_hblob.alloc(hoff + 16)) != ACCG_OK) return st;
-  roff = hoff = 0;
-  for (int i = 0; i < n_regions; i++) {
-    if (reads_bytes[i]) ACCG_HIP(hipMemcpyAsync(b->d_rblob.p + roff, reads_ser[i], reads_bytes[i], hipMemcpyHostToDevice, s));
-    if (haps_bytes[i]) ACCG_HIP(hipMemcpyAsync(b->d_hblob.p + hoff, haps_ser[i], haps_bytes[i], hipMemcpyHostToDevice, s));
-    roff += reads_bytes[i]; hoff += haps_bytes[i];
-  }
-  if ((st = b->d_rd.upload(b->rd, s)) != ACCG_OK) return st;
-  if ((st = b->d_hp.upload(b->hp, s)) != ACCG_OK) return st;
-  if ((st = b->d_rd_out.upload(b->rd_out, s)) != ACCG_OK) return st;
-  if ((st = b->d_hp_local.upload(b->hp_local, s)) != ACCG_OK) return st;
-  if ((st = b->d_hap_ids.upload(b->hap_ids, s)) != ACCG_OK) return st;
-  if ((st = b->d_work.upload(b->work, s)) != ACCG_OK) return st;
-  if ((st = b->d_out.alloc(b->pairs + 1)) != ACCG_OK) return st;
-  if ((st = b->d_out64.alloc(b->pairs + 1)) != ACCG_OK) return st;
   b->rescue_cap = 0;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b->rescue_cap = std::max(b->rescue_cap, b->rescue_bound[c]);
-  if ((st = b->d_regions.upload(b->regions_dev, s)) != ACCG_OK) return st;
-  if ((st = b->d_chunks.upload(b->chunks_dev, s)) != ACCG_OK) return st;
-  if ((st = b->d_sorted_reads.upload(b->sorted_reads, s)) != ACCG_OK) return st;
-  if ((st = b->d_flagged.alloc(b->rd.size() + 1)) != ACCG_OK) return st;
-  if ((st = b->d_state.alloc(state_words(*b))) != ACCG_OK) return st;
-  if ((st = b->d_rescue_jobs.alloc((size_t)b->rescue_cap * PHMM_RESCUE_CLASSES + 1)) != ACCG_OK) return st;
-  ACCG_HIP(hipMemsetAsync(b->d_out.p, 0, (b->pairs + 1) * sizeof(float), s));
-  ACCG_HIP(hipMemsetAsync(b->d_out64.p, 0, (b->pairs + 1) * sizeof(double), s));
-  ACCG_HIP(hipStreamSynchronize(s));   // the caller's host buffers may go away after this returns
+  // One device arena: [uploaded tables and blobs][scratch][state | results].  The uploaded part is assembled in the context's
+  // pinned staging and goes over in a single copy; the last words of `state` (n_rescued) sit right in front of `out`, so the
+  // results come back in a single copy too.
+  size_t off = 0;
+  auto take = [&](size_t bytes, size_t align = 256) { off = (off + align - 1) / align * align; const size_t o = off; off += bytes; return o; };
+  auto vbytes = [](const auto& v) { return v.size() * sizeof(v[0]); };
+  const size_t o_rblob = take(roff + 16), o_hblob = take(hoff + 16), o_rd = take(vbytes(b->rd)), o_hp = take(vbytes(b->hp)),
+               o_rd_out = take(vbytes(b->rd_out)), o_hp_local = take(vbytes(b->hp_local)), o_hap_ids = take(vbytes(b->hap_ids)),
+               o_work = take(vbytes(b->work)), o_regions = take(vbytes(b->regions_dev)), o_chunks = take(vbytes(b->chunks_dev)),
+               o_sorted = take(vbytes(b->sorted_reads));
+  const size_t upload_bytes = off;
+  const size_t o_flagged = take((b->rd.size() + 1) * sizeof(uint32_t));
+  const size_t o_jobs = take(((size_t)b->rescue_cap * PHMM_RESCUE_CLASSES + 1) * sizeof(PhmmWork));
+  const size_t o_out64 = take((b->pairs + 1) * sizeof(double));
+  const size_t sw = state_words(*b);                         // even: the u64 counter at its end is 8-byte aligned
+  const size_t o_state = take((sw + (sw & 1)) * sizeof(uint32_t) + (b->pairs + 1) * sizeof(float));
+  const size_t o_out = o_state + (sw + (sw & 1)) * sizeof(uint32_t);
+  if ((st = b->d_arena.alloc(off + 256)) != ACCG_OK) return st;
+  uint8_t* base = b->d_arena.p;
+  b->d_rblob.place(base, o_rblob, roff + 16); b->d_hblob.place(base, o_hblob, hoff + 16);
+  b->d_rd.place(base, o_rd, b->rd.size()); b->d_hp.place(base, o_hp, b->hp.size());
+  b->d_rd_out.place(base, o_rd_out, b->rd_out.size()); b->d_hp_local.place(base, o_hp_local, b->hp_local.size());
+  b->d_hap_ids.place(base, o_hap_ids, b->hap_ids.size()); b->d_work.place(base, o_work, b->work.size());
+  b->d_regions.place(base, o_regions, b->regions_dev.size()); b->d_chunks.place(base, o_chunks, b->chunks_dev.size());
+  b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
+  b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
+  b->d_rescue_jobs.place(base, o_jobs, (size_t)b->rescue_cap * PHMM_RESCUE_CLASSES + 1);
+  b->d_out64.place(base, o_out64, b->pairs + 1);
+  b->d_state.place(base, o_state, sw);
+  b->d_out.place(base, o_out, b->pairs + 1);
+  b->res_off = o_out - sizeof(unsigned long long);
+  if (state_nresc(*b) * sizeof(uint32_t) + o_state != b->res_off) return ACCG_ERR_BAD_ARG;   // layout invariant of the single D2H
+  void* stage_v = nullptr;
+  ACCG_HIP(ctx_stage(ctx, upload_bytes + 16, &stage_v));
+  uint8_t* stage = (uint8_t*)stage_v;
+  roff = hoff = 0;
+  for (int i = 0; i < n_regions; i++) {
+    if (reads_bytes[i]) memcpy(stage + o_rblob + roff, reads_ser[i], reads_bytes[i]);
+    if (haps_bytes[i]) memcpy(stage + o_hblob + hoff, haps_ser[i], haps_bytes[i]);
+    roff += reads_bytes[i]; hoff += haps_bytes[i];
+  }
+  memset(stage + o_rblob + roff, 0, 16); memset(stage + o_hblob + hoff, 0, 16);
+  auto put = [&](size_t o, const auto& v) { if (!v.empty()) memcpy(stage + o, v.data(), vbytes(v)); };
+  put(o_rd, b->rd); put(o_hp, b->hp); put(o_rd_out, b->rd_out); put(o_hp_local, b->hp_local); put(o_hap_ids, b->hap_ids);
+  put(o_work, b->work); put(o_regions, b->regions_dev); put(o_chunks, b->chunks_dev); put(o_sorted, b->sorted_reads);
+  if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
+  ACCG_HIP(hipMemsetAsync(base + o_out64, 0, (o_out - o_out64) + (b->pairs + 1) * sizeof(float), s));   // out64, state, out
+  ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
+  if (getenv("ACCG_TRACE")) fprintf(stderr, "accg_phmm_batch_create: partition %.0f us, arena + upload %.0f us\n", std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count());
   *out = b.release();
   return ACCG_OK;
 }
@@ -596,19 +719,28 @@ extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, doubl
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  // one copy: [n_rescued][out f32]; a second one for the fp64 values only when something was rescued
+  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float);
+  const size_t head_al = (head + 7) / 8 * 8;
+  void* stage_v = nullptr;
+  ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));
+  uint8_t* stage = (uint8_t*)stage_v;
+  ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   unsigned long long nresc = 0;
-  ACCG_HIP(hipMemcpy(&nresc, b->d_state.p + state_nresc(*b), sizeof nresc, hipMemcpyDeviceToHost));
-  std::vector<float> tmp;
-  float* raw = out_raw;
-  if (!raw && out_log10) { tmp.resize(b->pairs); raw = tmp.data(); }
-  if (raw && b->pairs) ACCG_HIP(hipMemcpy(raw, b->d_out.p, b->pairs * sizeof(float), hipMemcpyDeviceToHost));
-  if (out_log10 && b->pairs) {
-    std::vector<double> r64;
-    if (nresc) { r64.resize(b->pairs); ACCG_HIP(hipMemcpy(r64.data(), b->d_out64.p, b->pairs * sizeof(double), hipMemcpyDeviceToHost)); }
+  memcpy(&nresc, stage, sizeof nresc);
+  const float* raw = (const float*)(stage + sizeof nresc);
+  if (out_raw && n) memcpy(out_raw, raw, n * sizeof(float));
+  if (out_log10 && n) {
+    const double* r64 = (const double*)(stage + head_al);
+    if (nresc) {
+      ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+      ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+    }
     const HostTables& t = host_tables();
     // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
-#pragma omp parallel for schedule(static) num_threads(accg::host_threads())
-    for (int64_t i = 0; i < (int64_t)b->pairs; i++) {
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n > 4096)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
       if (raw[i] < PHMM_MIN_ACCEPTED) out_log10[i] = log10(r64[i]) - t.log10_init_d;
       else out_log10[i] = (double)(log10f(raw[i]) - t.log10_init_f);
     }
@@ -621,10 +753,7 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
-  b->d_rblob.release(); b->d_hblob.release(); b->d_rd.release(); b->d_hp.release(); b->d_rd_out.release();
-  b->d_hp_local.release(); b->d_hap_ids.release(); b->d_work.release(); b->d_out.release(); b->d_out64.release();
-  b->d_regions.release(); b->d_chunks.release(); b->d_sorted_reads.release(); b->d_flagged.release();
-  b->d_state.release(); b->d_rescue_jobs.release();
+  b->d_arena.release();
   delete b;
 }
 
@@ -644,21 +773,34 @@ extern "C" int accg_phmm_region_f64(accg_ctx* ctx, const void* reads_ser, size_t
 
 extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
                                 size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* cnt) {
+  static const bool trace = getenv("ACCG_TRACE") != nullptr;     // stage timings of the one-shot path on stderr
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
   accg_phmm_batch* b = nullptr;
   const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
   size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
   int st = accg_phmm_batch_create(ctx, 1, rs, rb, hs, hb, &b);
   if (st != ACCG_OK) return st;
+  const auto t1 = clk::now();
   hipEventRecord(ctx->ev0, ctx->stream);
   st = accg_phmm_batch_run(b, mode);
   hipEventRecord(ctx->ev1, ctx->stream);
+  auto t2 = t1, t3 = t1;
   if (st == ACCG_OK) {
     if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
       float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
       b->last_kernel_ns = (uint64_t)((double)ms * 1e6);
     }
+    t2 = clk::now();
     st = accg_phmm_batch_results(b, out_raw, out_log10, cnt);
+    t3 = clk::now();
   }
+  const uint64_t kernel_ns = b->last_kernel_ns, pairs = b->pairs;
   accg_phmm_batch_destroy(b);
+  if (trace) {
+    auto us = [](clk::time_point a, clk::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
+    fprintf(stderr, "accg_phmm_region: %llu pairs: create %.0f us, run+wait %.0f us (kernels %.0f us), results %.0f us, destroy %.0f us\n",
+            (unsigned long long)pairs, us(t0, t1), us(t1, t2), kernel_ns / 1e3, us(t2, t3), us(t3, clk::now()));
+  }
   return st;
 }
