@@ -6,6 +6,9 @@
  *
  * There is no CPU fallback behind this ABI: if no gfx950 device is present, accg_init() fails with
  * ACCG_ERR_NO_DEVICE and every other call with ACCG_ERR_NOT_INITIALISED.
+ *
+ * A context owns its HIP streams, a cache of device blocks and a pinned staging buffer: use it from one host thread at a
+ * time (one context per thread for concurrent callers) and destroy its batches before accg_shutdown().
  */
 #ifndef ACCG_H
 #define ACCG_H
