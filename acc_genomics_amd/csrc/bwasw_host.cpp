@@ -21,7 +21,7 @@ struct accg_bwasw_batch {
   struct Launch { int K, side; uint32_t work_off, n_work; };
   std::vector<Launch> launches;
   uint64_t cells = 0;
-  ~accg_bwasw_batch() { for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) hipFree(p); }
+  ~accg_bwasw_batch() { for (void* p : {(void*)d_blob, (void*)d_seeds, (void*)d_work, (void*)d_out}) if (p) ctx->pool.put(p); }
 };
 
 extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const uint8_t* seqs, const uint32_t* seq_off,
@@ -88,10 +88,10 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
       b->launches.push_back(L);
     }
   }
-  ACCG_HIP(hipMalloc((void**)&b->d_blob, blob.size()));
-  ACCG_HIP(hipMalloc((void**)&b->d_seeds, std::max<size_t>(n_seeds, 1) * sizeof(BwaswSeed)));
-  ACCG_HIP(hipMalloc((void**)&b->d_work, std::max<size_t>(work.size(), 1) * sizeof(BwaswWork)));
-  ACCG_HIP(hipMalloc((void**)&b->d_out, std::max<size_t>(n_seeds, 1) * 8 * sizeof(int16_t)));
+  ACCG_HIP(ctx->pool.get(blob.size(), (void**)&b->d_blob));
+  ACCG_HIP(ctx->pool.get(std::max<size_t>(n_seeds, 1) * sizeof(BwaswSeed), (void**)&b->d_seeds));
+  ACCG_HIP(ctx->pool.get(std::max<size_t>(work.size(), 1) * sizeof(BwaswWork), (void**)&b->d_work));
+  ACCG_HIP(ctx->pool.get(std::max<size_t>(n_seeds, 1) * 8 * sizeof(int16_t), (void**)&b->d_out));
   ACCG_HIP(hipMemcpy(b->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (n_seeds) {
     ACCG_HIP(hipMemcpy(b->d_seeds, seeds.data(), n_seeds * sizeof(BwaswSeed), hipMemcpyHostToDevice));

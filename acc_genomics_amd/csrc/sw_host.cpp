@@ -14,8 +14,14 @@ using namespace accg;
 
 namespace {
 struct SwLaunch { int K, lpp; bool pack16, lane_is_alt; uint32_t work0, n_work; int sweep_cap; };
-template <typename T> int dev_upload(T** dst, const void* src, size_t bytes, hipStream_t s) {
-  ACCG_HIP(hipMalloc((void**)dst, bytes ? bytes : 16));
+// device blocks come from the context's cache (accg_internal.h): FalconSWFPGA_run builds and drops a batch per call
+template <typename T> int dev_alloc(accg_ctx* c, T** dst, size_t bytes) {
+  ACCG_HIP(c->pool.get(bytes ? bytes : 16, (void**)dst));
+  return ACCG_OK;
+}
+template <typename T> int dev_upload(accg_ctx* c, T** dst, const void* src, size_t bytes, hipStream_t s) {
+  int st = dev_alloc(c, dst, bytes);
+  if (st != ACCG_OK) return st;
   if (bytes) ACCG_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
   return ACCG_OK;
 }
@@ -34,14 +40,12 @@ struct accg_sw_batch {
   uint4* d_bt = nullptr; uint64_t bt_bytes = 0;
   int32_t *d_cig_n = nullptr, *d_cig_off = nullptr, *d_cig_el = nullptr, *d_cig_packed = nullptr;
   unsigned long long *d_cig_start = nullptr, *d_cig_total = nullptr;
-  int32_t* h_packed = nullptr; uint64_t h_packed_cap = 0;   // pinned staging for the slot-form readback
   int max_el = 0;
   ~accg_sw_batch() {            // also reached on the error paths of accg_sw_batch_create
     for (void* p : {(void*)d_refs, (void*)d_alts, (void*)d_strat, (void*)d_rl, (void*)d_al, (void*)d_score, (void*)d_p1, (void*)d_p2,
                     (void*)d_work, (void*)d_bt, (void*)d_cig_n, (void*)d_cig_off, (void*)d_cig_el, (void*)d_cig_packed,
                     (void*)d_cig_start, (void*)d_cig_total})
-      if (p) hipFree(p);
-    if (h_packed) hipHostFree(h_packed);
+      if (p) ctx->pool.put(p);
   }
 };
 
@@ -116,15 +120,15 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   if (strategies) memcpy(strat.data(), strategies, n);
   const size_t rbytes = ref_stride ? ref_stride * (size_t)n : (size_t)max_rl, abytes = alt_stride ? alt_stride * (size_t)n : (size_t)max_al;
   int st;
-  if ((st = dev_upload(&b->d_refs, refs, rbytes, s)) != ACCG_OK) return st;
-  if ((st = dev_upload(&b->d_alts, alts, abytes, s)) != ACCG_OK) return st;
-  if ((st = dev_upload(&b->d_rl, ref_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
-  if ((st = dev_upload(&b->d_al, alt_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
-  if ((st = dev_upload(&b->d_strat, strat.data(), n, s)) != ACCG_OK) return st;
-  if ((st = dev_upload(&b->d_work, work.data(), sizeof(SwWork) * work.size(), s)) != ACCG_OK) return st;
-  ACCG_HIP(hipMalloc((void**)&b->d_score, sizeof(int32_t) * std::max(n, 1)));
-  ACCG_HIP(hipMalloc((void**)&b->d_p1, sizeof(int32_t) * std::max(n, 1)));
-  ACCG_HIP(hipMalloc((void**)&b->d_p2, sizeof(int32_t) * std::max(n, 1)));
+  if ((st = dev_upload(ctx, &b->d_refs, refs, rbytes, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(ctx, &b->d_alts, alts, abytes, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(ctx, &b->d_rl, ref_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(ctx, &b->d_al, alt_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(ctx, &b->d_strat, strat.data(), n, s)) != ACCG_OK) return st;
+  if ((st = dev_upload(ctx, &b->d_work, work.data(), sizeof(SwWork) * work.size(), s)) != ACCG_OK) return st;
+  if ((st = dev_alloc(ctx, &b->d_score, sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
+  if ((st = dev_alloc(ctx, &b->d_p1, sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
+  if ((st = dev_alloc(ctx, &b->d_p2, sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
   ACCG_HIP(hipStreamSynchronize(s));
   SwArgs& a = b->args;
   a.refs = b->d_refs; a.alts = b->d_alts; a.ref_stride = (uint32_t)ref_stride; a.alt_stride = (uint32_t)alt_stride;
@@ -156,14 +160,14 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   const size_t n1 = (size_t)std::max(b->n, 1);
   if (max_el != b->max_el) {
     ACCG_HIP(hipStreamSynchronize(s));
-    if (b->d_cig_el) { hipFree(b->d_cig_el); b->d_cig_el = nullptr; }
-    if (b->d_cig_packed) { hipFree(b->d_cig_packed); b->d_cig_packed = nullptr; }
-    ACCG_HIP(hipMalloc((void**)&b->d_cig_el, n1 * max_el * 2 * sizeof(int32_t)));
-    ACCG_HIP(hipMalloc((void**)&b->d_cig_packed, n1 * max_el * 2 * sizeof(int32_t)));
-    if (!b->d_cig_start) ACCG_HIP(hipMalloc((void**)&b->d_cig_start, n1 * sizeof(unsigned long long)));
-    if (!b->d_cig_total) ACCG_HIP(hipMalloc((void**)&b->d_cig_total, sizeof(unsigned long long)));
-    if (!b->d_cig_n) ACCG_HIP(hipMalloc((void**)&b->d_cig_n, n1 * sizeof(int32_t)));
-    if (!b->d_cig_off) ACCG_HIP(hipMalloc((void**)&b->d_cig_off, n1 * sizeof(int32_t)));
+    if (b->d_cig_el) { b->ctx->pool.put(b->d_cig_el); b->d_cig_el = nullptr; }
+    if (b->d_cig_packed) { b->ctx->pool.put(b->d_cig_packed); b->d_cig_packed = nullptr; }
+    { int st_ = dev_alloc(b->ctx, &b->d_cig_el, n1 * max_el * 2 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
+    { int st_ = dev_alloc(b->ctx, &b->d_cig_packed, n1 * max_el * 2 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
+    if (!b->d_cig_start) { int st_ = dev_alloc(b->ctx, &b->d_cig_start, n1 * sizeof(unsigned long long)); if (st_ != ACCG_OK) return st_; }
+    if (!b->d_cig_total) { int st_ = dev_alloc(b->ctx, &b->d_cig_total, sizeof(unsigned long long)); if (st_ != ACCG_OK) return st_; }
+    if (!b->d_cig_n) { int st_ = dev_alloc(b->ctx, &b->d_cig_n, n1 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
+    if (!b->d_cig_off) { int st_ = dev_alloc(b->ctx, &b->d_cig_off, n1 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
     b->max_el = max_el;
   }
   uint64_t limit = 16ull << 30;
@@ -177,9 +181,9 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   }
   if (need > b->bt_bytes) {
     ACCG_HIP(hipStreamSynchronize(s));
-    if (b->d_bt) hipFree(b->d_bt);
+    if (b->d_bt) b->ctx->pool.put(b->d_bt);
     b->d_bt = nullptr; b->bt_bytes = 0;
-    ACCG_HIP(hipMalloc((void**)&b->d_bt, need));
+    { int st_ = dev_alloc(b->ctx, &b->d_bt, need); if (st_ != ACCG_OK) return st_; }
     b->bt_bytes = need;
   }
   SwArgs a = b->args;
@@ -231,14 +235,10 @@ extern "C" int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* of
   uint64_t tot = 0;
   int st = accg_sw_batch_cigars_packed(b, cnt.data(), offsets, starts.data(), nullptr, 0, &tot);
   if (st != ACCG_OK) return st;
-  if (tot > b->h_packed_cap) {
-    if (b->h_packed) hipHostFree(b->h_packed);
-    b->h_packed = nullptr; b->h_packed_cap = 0;
-    ACCG_HIP(hipHostMalloc((void**)&b->h_packed, tot * 2 * sizeof(int32_t), hipHostMallocDefault));
-    b->h_packed_cap = tot;
-  }
-  const int32_t* packed = b->h_packed;
-  st = accg_sw_batch_cigars_packed(b, nullptr, nullptr, nullptr, b->h_packed, tot, nullptr);
+  void* stage = nullptr;                                   // the context's pinned staging
+  ACCG_HIP(ctx_stage(b->ctx, tot * 2 * sizeof(int32_t) + 16, &stage));
+  const int32_t* packed = (const int32_t*)stage;
+  st = accg_sw_batch_cigars_packed(b, nullptr, nullptr, nullptr, (int32_t*)stage, tot, nullptr);
   if (st != ACCG_OK) return st;
   const size_t slot = (size_t)b->max_el * 2;
 #pragma omp parallel for schedule(static) num_threads(accg::host_threads())
