@@ -162,3 +162,71 @@ extern "C" void accg_bwasw_batch_destroy(accg_bwasw_batch* b) {
   hipStreamSynchronize(b->ctx->stream);
   delete b;
 }
+
+// ---- the FPGA kernel's own buffers ------------------------------------------------------------------------------------
+// sw_top(input, output, pac_input, size) (bwa-sw/sdaccel/smithwaterman.cpp:1046-1054) takes the host's int stream as it is:
+// per read  [index of the next read's record][read_len][ceil(read_len/8) ints, 8 bases each, 4 bits, first base on top]
+//           [chain_num] then per chain [rmax0 lo][rmax0 hi][rmax1 lo][rmax1 hi][seed_num] and per seed
+//           [seed_index][rbeg lo][rbeg hi][qbeg][seed_len]                       (data_parse :311-458, main_cl.cpp:73-90),
+// and the 2-bit packed reference (16 bases per int, base k at bits 2k; read_proc :727-757).  The sequences of a seed are cut
+// out as read_proc does (:775-806): left query = read[qbeg-1 .. 0], right query = read[qbeg+len ..], left target =
+// ref[rbeg-1 .. rmax0], right target = ref[rbeg+len .. rmax1).  Results: five ints per seed in input order.
+extern "C" int accg_bwasw_records(accg_ctx* ctx, const int32_t* input, int64_t size, const uint32_t* pac, uint64_t pac_words,
+                                  int32_t* results, int64_t results_cap, int64_t* n_tasks) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!input || size < 0 || !pac || !n_tasks) return ACCG_ERR_BAD_ARG;
+  std::vector<uint8_t> seqs;
+  std::vector<uint32_t> off;
+  std::vector<uint16_t> par;
+  std::vector<uint8_t> read, ref;
+  int64_t k = 0;
+  auto need = [&](int64_t m) { return k + m <= size; };
+  while (k < size) {
+    if (!need(2)) return ACCG_ERR_BAD_WIRE;
+    k++;                                                   // index of the next record (the device's readEndIndex)
+    const int64_t read_len = input[k++];
+    if (read_len < 0 || read_len > 511 || !need((read_len + 7) / 8 + 1)) return ACCG_ERR_BAD_WIRE;   // read_seq[512]
+    read.resize((size_t)read_len);
+    for (int64_t i = 0; i < read_len; i++) read[(size_t)i] = (uint8_t)(((uint32_t)input[k + i / 8] >> (28 - 4 * (i & 7))) & 0xF);
+    k += (read_len + 7) / 8;
+    const int64_t chain_num = input[k++];
+    if (chain_num < 0) return ACCG_ERR_BAD_WIRE;
+    for (int64_t c = 0; c < chain_num; c++) {
+      if (!need(5)) return ACCG_ERR_BAD_WIRE;
+      const uint64_t rmax0 = (uint32_t)input[k] | ((uint64_t)(uint32_t)input[k + 1] << 32);
+      const uint64_t rmax1 = (uint32_t)input[k + 2] | ((uint64_t)(uint32_t)input[k + 3] << 32);
+      k += 4;
+      const int64_t seed_num = input[k++];
+      if (seed_num < 0 || rmax1 < rmax0 || rmax1 - rmax0 > 2048 || (rmax1 >> 4) >= pac_words || !need(5 * seed_num)) return ACCG_ERR_BAD_WIRE;
+      ref.resize((size_t)(rmax1 - rmax0));                 // chain_rseqs[2048]
+      for (uint64_t p = rmax0; p < rmax1; p++) ref[(size_t)(p - rmax0)] = (uint8_t)((pac[p >> 4] >> ((p & 15) << 1)) & 3);
+      for (int64_t sd = 0; sd < seed_num; sd++) {
+        const int32_t seed_index = input[k];
+        const uint64_t rbeg = (uint32_t)input[k + 1] | ((uint64_t)(uint32_t)input[k + 2] << 32);
+        const int64_t qbeg = input[k + 3], seed_len = input[k + 4];
+        k += 5;
+        if (qbeg < 0 || seed_len < 0 || qbeg + seed_len > read_len || rbeg < rmax0 || rbeg + (uint64_t)seed_len > rmax1) return ACCG_ERR_BAD_WIRE;
+        const int64_t lq = qbeg, rq = read_len - qbeg - seed_len, lr = (int64_t)(rbeg - rmax0), rr = (int64_t)(rmax1 - rbeg) - seed_len;
+        if (lq > 0xFFFF || lr > 0xFFFF || rq > 0xFFFF || rr > 0xFFFF) return ACCG_ERR_TOO_LONG;
+        off.push_back((uint32_t)seqs.size());
+        for (int64_t i = 0; i < lq; i++) seqs.push_back(read[(size_t)(lq - 1 - i)]);
+        for (int64_t i = 0; i < rq; i++) seqs.push_back(read[(size_t)(qbeg + seed_len + i)]);
+        for (int64_t i = 0; i < lr; i++) seqs.push_back(ref[(size_t)(lr - 1 - i)]);
+        for (int64_t i = 0; i < rr; i++) seqs.push_back(ref[(size_t)(lr + seed_len + i)]);
+        const uint16_t p7[7] = {(uint16_t)lq, (uint16_t)lr, (uint16_t)rq, (uint16_t)rr, (uint16_t)seed_len, (uint16_t)qbeg, (uint16_t)seed_index};
+        par.insert(par.end(), p7, p7 + 7);
+      }
+    }
+  }
+  *n_tasks = (int64_t)off.size();
+  if (!results) return ACCG_OK;                            // size query (main_cl.cpp:73-90 counts the tasks the same way)
+  if (results_cap < *n_tasks * 5) return ACCG_ERR_BAD_ARG;
+  seqs.resize(seqs.size() + 8, 4);
+  accg_bwasw_batch* b = nullptr;
+  int st = accg_bwasw_batch_create(ctx, (uint32_t)off.size(), seqs.data(), off.data(), par.data(), &b);
+  if (st != ACCG_OK) return st;
+  st = accg_bwasw_batch_run(b);
+  if (st == ACCG_OK) st = accg_bwasw_batch_results(b, nullptr, results);
+  accg_bwasw_batch_destroy(b);
+  return st;
+}

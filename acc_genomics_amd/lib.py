@@ -85,6 +85,7 @@ def load():
     L.accg_bwasw_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_bwasw_batch_results.argtypes = [vp, vp, vp]
     L.accg_bwasw_batch_destroy.argtypes = [vp]
+    L.accg_bwasw_records.argtypes = [vp, vp, C.c_int64, vp, C.c_uint64, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.accg_phmm_tables_f32.argtypes = [vp, vp, vp, vp]
     L.accg_phmm_tables_f64.argtypes = [vp, vp, vp, vp]
     _lib = L
@@ -315,6 +316,17 @@ class SmemBatch:
 
     def __exit__(self, *a):
         self.close()
+
+
+def bwasw_records(ctx, stream, pac):
+    """accg_bwasw_records: the FPGA host's int stream + 2-bit packed reference -> int32[n_tasks, 5] result words."""
+    stream = np.ascontiguousarray(stream, dtype=np.int32)
+    pac = np.ascontiguousarray(pac, dtype=np.uint32)
+    n = C.c_int64()
+    _check(ctx.L.accg_bwasw_records(ctx.h, stream.ctypes.data, len(stream), pac.ctypes.data, len(pac), None, 0, C.byref(n)))
+    out = np.zeros((n.value, 5), np.int32)
+    _check(ctx.L.accg_bwasw_records(ctx.h, stream.ctypes.data, len(stream), pac.ctypes.data, len(pac), out.ctypes.data, out.size, C.byref(n)))
+    return out
 
 
 class BwaswBatch:

@@ -175,6 +175,12 @@ int accg_bwasw_batch_run(accg_bwasw_batch* b);
 int accg_bwasw_batch_time(accg_bwasw_batch* b, int warmup, int iters, float* ms_per_run);
 int accg_bwasw_batch_results(accg_bwasw_batch* b, int16_t* fields, int32_t* words);
 void accg_bwasw_batch_destroy(accg_bwasw_batch* b);
+/* The FPGA kernel's own buffers, sw_top(input, output, pac_input, size) (smithwaterman.cpp:1046-1054): `input` is the host's
+ * int stream of reads / chains / seeds (data_parse :311-458, written by the bwa-flow host, re-read in main_cl.cpp:73-90),
+ * `pac` the 2-bit packed reference (16 bases per int).  results = five ints per seed (:666-670) in input order (the FPGA
+ * emits them in completion order, seed_index identifies them).  results == NULL only counts the tasks into *n_tasks. */
+int accg_bwasw_records(accg_ctx* ctx, const int32_t* input, int64_t size, const uint32_t* pac, uint64_t pac_words,
+                       int32_t* results, int64_t results_cap, int64_t* n_tasks);
 
 /* ---- counters (multi-GPU) ---------------------------------------------------------------------
  * Packs counters into the uint64[4] {cells, pairs, kernel_ns, rescued} vector that the ranks

@@ -110,3 +110,58 @@ def test_empty_batch_and_limits(ctx):
         BwaswBatch(ctx, np.zeros(600, np.uint8), np.zeros(1, np.uint32), np.array([[255, 10, 0, 0, 19, 255, 0]], np.uint16))
     with pytest.raises(AccgError):
         BwaswBatch(ctx, np.zeros(4000, np.uint8), np.zeros(1, np.uint32), np.array([[10, 2048, 0, 0, 19, 10, 0]], np.uint16))
+
+
+def test_fpga_record_stream(ctx):
+    """accg_bwasw_records takes sw_top's own buffers: the int stream of reads / chains / seeds and the 2-bit packed
+    reference.  The stream is written here the way data_parse / read_proc read it; the expected words come from the oracle
+    run on sequences cut directly out of the arrays."""
+    from acc_genomics_amd.lib import bwasw_records
+    rng = np.random.default_rng(45)
+    G = 60000
+    genome = rng.integers(0, 4, size=G).astype(np.uint8)
+    pac = np.zeros((G + 15) // 16 + 1, np.uint32)
+    for k in range(16):
+        part = genome[k::16].astype(np.uint32) << np.uint32(2 * k)
+        pac[:len(part)] |= part
+    stream, seqs, offs, pars = [], [], [], []
+    pos = 0
+    idx = 0
+    for r in range(300):
+        rl = int(rng.integers(60, 251))
+        g0 = int(rng.integers(400, G - 1200))
+        read = genome[g0:g0 + rl].copy()
+        m = rng.random(rl) < 0.03
+        read[m] = rng.integers(0, 4, size=int(m.sum()))
+        if rng.random() < 0.3: read[int(rng.integers(0, rl))] = 4
+        rec = [rl]
+        for i in range(0, rl, 8):
+            w = 0
+            for j in range(8):
+                w = (w << 4) | (int(read[i + j]) if i + j < rl else 0)
+            rec.append(w - (1 << 32) if w >= (1 << 31) else w)
+        n_chain = int(rng.integers(0, 3))
+        rec.append(n_chain)
+        for c in range(n_chain):
+            rmax0 = g0 - int(rng.integers(0, 200)); rmax1 = g0 + rl + int(rng.integers(0, 200))
+            rec += [rmax0 & 0xFFFFFFFF, rmax0 >> 32, rmax1 & 0xFFFFFFFF, rmax1 >> 32]
+            n_seed = int(rng.integers(0, 4))
+            rec.append(n_seed)
+            for s in range(n_seed):
+                sl = int(rng.integers(19, min(60, rl) + 1)); qb = int(rng.integers(0, rl - sl + 1))
+                rbeg = g0 + qb
+                rec += [idx & 0x7FFF, rbeg & 0xFFFFFFFF, rbeg >> 32, qb, sl]
+                lq, rq, lr, rr = qb, rl - qb - sl, rbeg - rmax0, rmax1 - rbeg - sl
+                sq = np.concatenate([read[:qb][::-1], read[qb + sl:], genome[rmax0:rbeg][::-1], genome[rbeg + sl:rmax1]]).astype(np.uint8)
+                seqs.append(sq); offs.append(pos); pos += len(sq)
+                pars.append([lq, lr, rq, rr, sl, qb, idx & 0x7FFF]); idx += 1
+        stream += [len(stream) + 1 + len(rec)] + rec            # first word: where the next read's record starts
+    want = _oracle(np.concatenate(seqs + [np.zeros(4, np.uint8)]), np.array(offs, np.uint32), np.array(pars, np.uint16))
+    got = bwasw_records(ctx, np.array(stream, np.int64).astype(np.int32), pac)
+    assert got.shape == (len(pars), 5) and len(pars) > 200
+    assert (got[:, 0] == np.array(pars)[:, 6]).all()
+    f = np.stack([(got[:, 1] & 0xFFFF), (got[:, 1] >> 16) & 0xFFFF, (got[:, 2] & 0xFFFF), (got[:, 2] >> 16) & 0xFFFF,
+                  (got[:, 3] & 0xFFFF), (got[:, 3] >> 16) & 0xFFFF, got[:, 4] & 0xFFFF], axis=1).astype(np.uint16).view(np.int16)
+    assert np.array_equal(f, want)
+    with pytest.raises(AccgError):                              # a truncated stream is refused, not read past its end
+        bwasw_records(ctx, np.array(stream[:len(stream) - 3], np.int64).astype(np.int32), pac)
