@@ -162,17 +162,30 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
             b.run_cigar(48)
         b.cigars()
         cigar_ms = (time.perf_counter() - tc0) / 2 * 1e3
+        check = None
+        if with_cpu:                                    # the measured batch against the oracle on a sample (checker only, untimed)
+            import orc
+            O = orc.oracle()
+            n_el, coff, el = b.cigars()
+            sc, p1, p2 = b.results()
+            ok, idxs = True, np.random.default_rng(0).choice(b.n, 256, replace=False)
+            for k in idxs:
+                wsc, wp1, wp2, woff, wcig, wn = orc.sw_pair(O, refs[k, :rl[k]].tobytes(), alts[k, :al[k]].tobytes(), int(strat[k]))
+                ok &= (sc[k], p1[k], p2[k], coff[k], n_el[k]) == (wsc, wp1, wp2, woff, wn)
+                ok &= list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig
+            check = {"pairs_checked": len(idxs), "equal_to_oracle": bool(ok)}
         ach = b.algorithmic_bytes / (k_ms * 1e-3) / 1e9
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         sw_traffic = json.load(open(tr)).get("sw_c2", {}).get("hbm_bytes_per_launch") if os.path.exists(tr) else None
         extras = {"kernel_ms": k_ms, "pairs_per_gpu": b.n, "cells_per_gpu": b.cells,
                   "with_cigar": {"ms_per_step": cigar_ms, "value": b.cells / (cigar_ms * 1e-3) / 1e9, "unit": "GCUPS",
-                                 "note": "fill + backtrace + D2H of 48-element CIGAR slots, wall clock"},
+                                 "note": "fill + backtrace + CIGARs back in 48-element host slots, wall clock"},
                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": sw_traffic, "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": b.algorithmic_bytes,
                                "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
                                         "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
+                  "oracle_check": check,
                   "cpu_baseline": cpu_baseline_sw(refs, rl, alts, al) if with_cpu else None}
     cells = b.cells * steps
     b.close()
@@ -219,6 +232,9 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
         th = host_cores()
         O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, S, 64, wout.ctypes.data, wnum.ctypes.data, th)
         lookups_per_read = O.orc_smem_last_lookups() / S
+        got, gnum = b.results()
+        smem_ok = bool(np.array_equal(gnum[:S], wnum) and all(np.array_equal(got[k, :min(gnum[k], 64)], wout[k, :min(wnum[k], 64)]) for k in range(S)))
+        del got
         algo = lookups_per_read * n_reads * 64.0            # 64-byte index blocks requested
         cpu = None
         if with_cpu:
@@ -236,6 +252,7 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
                                "kernel": "smem_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
                                "note": "64-byte index block per Occ lookup; the 64 MB index is served from L2 / Infinity Cache, the path is "
                                        "bound by dependent-lookup latency"},
+                  "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},
                   "cpu_baseline": cpu}
     reads_done = n_reads * steps
     b.close(); idx.close()
@@ -274,10 +291,13 @@ def bench_bwasw(ctx, rank, dist, torch, steps, with_cpu, n_seeds=1 << 18):
             c0 = time.perf_counter()
             O.orc_bwasw_batch(seqs.ctypes.data, off.ctypes.data, par.ctypes.data, S, out.ctypes.data, th)
             dt = time.perf_counter() - c0
+            got, _ = b.results()
+            bw_ok = bool(np.array_equal(got[:S], out))
             cpu = {"value": S / dt / 1e6, "unit": "Mseeds/s", "cores": th, "kind": "port",
                    "sample": "%d seeds through oracle/bwasw_oracle.c (restatement of bwa-sw/sdaccel/smithwaterman.cpp, FPGA device code "
                              "that cannot be built here), %.2f s wall" % (S, dt)}
         extras = {"kernel_ms": k_ms, "seeds_per_gpu": n_seeds, "rect_cells_per_gpu": b.cells, "cpu_baseline": cpu,
+                  "oracle_check": ({"seeds_checked": S, "equal_to_oracle": bw_ok} if with_cpu else None),
                   "note": "VALU-issue bound integer recurrence held in registers; HBM traffic is the sequences once (%d bytes)" % len(seqs)}
     done = n_seeds * steps
     b.close()
@@ -405,6 +425,19 @@ def main():
         if os.path.exists(tr):
             roof["traffic"] = json.load(open(tr)).get("phmm_c1", {}).get("hbm_bytes_per_launch")
         cpu = None if args.no_cpu_baseline else cpu_baseline_phmm(reads, haps)
+        check = None
+        if not args.no_cpu_baseline:                    # the measured batch against the oracle on a sample (checker only, untimed)
+            import orc
+            O = orc.oracle()
+            _, l10, _ = batch.results()
+            nh = len(haps)
+            worst = 0.0
+            idxs = np.random.default_rng(0).choice(batch.pairs, 256, replace=False)
+            for k in idxs:
+                pa = orc.pair_args(reads[k // nh], haps[k % nh])
+                want = O.orc_phmm_finish(O.orc_phmm_forward_f32(*pa, 0), *pa, None)
+                worst = max(worst, abs(l10[k] - want) / abs(want))
+            check = {"pairs_checked": len(idxs), "max_rel_err_log10": worst, "tolerance": 1e-5, "within_tolerance": bool(worst < 1e-5)}
         line = {
             "metric": "pairhmm_forward_gcups_fp32", "value": total_cells / wall / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -412,7 +445,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: PairHMM 2048 reads (101 bp) x 32 haplotypes (300 bp) = 65536 pairs per GPU, "
                                    "fp32 sweep + fp64 rescue pass, mode=%s" % args.mode,
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "oracle_check": check,
             "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
             "sw": sw, "smem": smem, "bwasw": bwasw,
         }
