@@ -168,3 +168,31 @@ def test_error_paths(ctx):
     # empty region is fine and yields nothing
     raw, l10, cnt = ctx.phmm_region(synth.serialize_reads([]), ok_h, 0)
     assert cnt.pairs == 0
+
+
+def test_mixed_length_regions_concurrent_classes(ctx):
+    """configs[3]-shaped batch at reduced size: regions with different read lengths put many (lanes, K) classes into one
+    batch, which the host launches side by side on forked streams; 10 % unrelated reads force the fp64 rescue classes too.
+    Strict mode must stay bit-exact with the oracle for every pair, fast mode within tolerance, on repeated runs."""
+    rng = synth.rng_for(303)
+    regs = []
+    for _ in range(96):
+        rl = int(rng.integers(30, 152)); hl = int(rng.integers(max(70, rl), 501))
+        regs.append(synth.make_region(rng, 32, 8, rl, hl, n_frac=0.01, unrelated_frac=0.10))
+    with A.PhmmBatch(ctx, [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]) as b:
+        b.run(A.ACCG_PHMM_STRICT)
+        raw, l10, cnt = b.results()
+        b.run(A.ACCG_PHMM_FAST)
+        _, l10f, cntf = b.results()
+        b.run(A.ACCG_PHMM_STRICT)
+        raw2, _, _ = b.results()
+    assert raw.tobytes() == raw2.tobytes()
+    off, resc = 0, 0
+    for reads, haps in regs:
+        oraw, ol10, r = _oracle_region(reads, haps)
+        n = len(reads) * len(haps)
+        assert raw[off:off + n].tobytes() == oraw.tobytes()
+        assert l10[off:off + n].tobytes() == ol10.tobytes()
+        assert np.max(np.abs(l10f[off:off + n] - ol10) / np.abs(ol10)) < REL_TOL
+        off += n; resc += r
+    assert cnt.rescued == resc and resc > 0
