@@ -423,7 +423,15 @@ def main():
                          "note": "12 algorithmic flop/cell (baseline_impl.cpp:84-86); the recurrence is VALU-issue bound, not HBM bound"}}
         tr = os.path.join(ROOT, "profiles", "traffic.json")     # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
         if os.path.exists(tr):
-            roof["traffic"] = json.load(open(tr)).get("phmm_c1", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tr)).get("phmm_c1", {})
+            roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            if tj.get("valu_insts_per_launch"):
+                # the roof this kernel actually runs under: wavefront VALU instructions (SQ_INSTS_VALU, PMC pass of the same
+                # workload) against the issue rate of a saturated SIMD (tools/ubench.hip: 1.04 ns per fp32 instruction at 8 waves)
+                ideal_ms = tj["valu_insts_per_launch"] / 1024.0 * 1.04e-6
+                roof["valu"]["issue"] = {"insts_per_launch": tj["valu_insts_per_launch"], "ns_per_inst_per_simd_at_full_occupancy": 1.04,
+                                         "ideal_ms": ideal_ms, "frac": ideal_ms / k_ms,
+                                         "note": "resident waves per SIMD are 2 at K = 13 (189 VGPRs); the same ubench issues at 1.35 ns there"}
         cpu = None if args.no_cpu_baseline else cpu_baseline_phmm(reads, haps)
         check = None
         if not args.no_cpu_baseline:                    # the measured batch against the oracle on a sample (checker only, untimed)
