@@ -336,7 +336,7 @@ class BwaswBatch:
     params uint16[n, 7] = {leftQlen, leftRlen, rightQlen, rightRlen, seed_len, seed_qbeg, seed_index}."""
 
     def __init__(self, ctx, seqs, seq_off, params):
-        self.L = ctx.L
+        self.ctx, self.L = ctx, ctx.L
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         off = np.ascontiguousarray(seq_off, dtype=np.uint32)
         par = np.ascontiguousarray(params, dtype=np.uint16).reshape(-1, 7)
