@@ -10,6 +10,7 @@ struct alignas(16) SmemIntv { uint64_t x0, x1, x2, info; };   // bwtintv_t: {x[0
 struct SmemArgs {
   const uint32_t* bwt;          // BWA block layout, 64 B per 128 symbols (smem/host/baseline.cpp:26-37)
   uint64_t primary, L2[5];
+  uint32_t compact;             // 1: re-laid-out index, 32 B per 64 symbols = 4 x u32 cumulative counts + 4 x 16 symbols (smem_host.cpp)
   const uint8_t* seq;           // n_reads x seq_stride codes (0-3, >= 4 ambiguous)
   const uint8_t* seq_len;
   uint32_t seq_stride, n_reads;

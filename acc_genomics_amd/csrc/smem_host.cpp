@@ -1,8 +1,10 @@
 // Host side of the SMEM seeding path: index upload (the role of ocl_init, smem/host/ocl.cpp:169-293) and read batches
 // (smem_ocl / ocl_kernel_invoke, :296-418).
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <vector>
 #include "accg_internal.h"
 #include "smem_dev.h"
 
@@ -12,6 +14,7 @@ struct accg_smem_index {
   accg_ctx* ctx = nullptr;
   uint32_t* d_bwt = nullptr;
   uint64_t words = 0, primary = 0, L2[5] = {0};
+  bool compact = false;
   ~accg_smem_index() { if (d_bwt) hipFree(d_bwt); }
 };
 
@@ -33,8 +36,38 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
   std::unique_ptr<accg_smem_index> x(new accg_smem_index);
   x->ctx = ctx; x->words = bwt_words; x->primary = bwt_para[0];
   for (int c = 0; c < 5; c++) x->L2[c] = bwt_para[1 + c];
+  // BWA's block (64 B per 128 symbols: 4 x u64 cumulative counts + 8 x 16 symbols) costs a lookup four 16-byte loads and
+  // eight words of popcounts.  While the counts fit 32 bits the index is re-laid-out on upload into half-blocks of the
+  // same total size, 32 B per 64 symbols = 4 x u32 counts + 4 x 16 symbols: one sector, two loads, four words per lookup.
+  // The counts a lookup returns are the same numbers.  ACCG_SMEM_COMPACT=0 keeps the caller's layout.
+  const uint64_t n_blocks = bwt_words / 16;
+  const char* ec = getenv("ACCG_SMEM_COMPACT");
+  x->compact = !(ec && ec[0] == '0') && n_blocks * 128 < (1ull << 32);
   ACCG_HIP(hipMalloc((void**)&x->d_bwt, bwt_words * 4));
-  ACCG_HIP(hipMemcpy(x->d_bwt, bwt, bwt_words * 4, hipMemcpyHostToDevice));
+  if (x->compact) {
+    std::vector<uint32_t> cb(bwt_words);
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads())
+    for (int64_t b = 0; b < (int64_t)n_blocks; b++) {
+      const uint32_t* src = bwt + b * 16;
+      uint32_t* d0 = cb.data() + b * 16;
+      uint32_t* d1 = d0 + 8;
+      uint32_t c[4];
+      for (int s = 0; s < 4; s++) c[s] = src[2 * s];              // low words of the u64 counts (high words are 0 here)
+      for (int s = 0; s < 4; s++) d0[s] = c[s];
+      for (int j = 0; j < 4; j++) {
+        const uint32_t v = src[8 + j];
+        d0[4 + j] = v;
+        const uint32_t lo = v & 0x55555555u, hi = (v >> 1) & 0x55555555u;
+        const uint32_t n1 = __builtin_popcount(lo & ~hi), n2 = __builtin_popcount(hi & ~lo), n3 = __builtin_popcount(hi & lo);
+        c[1] += n1; c[2] += n2; c[3] += n3; c[0] += 16 - n1 - n2 - n3;
+      }
+      for (int s = 0; s < 4; s++) d1[s] = c[s];
+      for (int j = 0; j < 4; j++) d1[4 + j] = src[12 + j];
+    }
+    ACCG_HIP(hipMemcpy(x->d_bwt, cb.data(), bwt_words * 4, hipMemcpyHostToDevice));
+  } else {
+    ACCG_HIP(hipMemcpy(x->d_bwt, bwt, bwt_words * 4, hipMemcpyHostToDevice));
+  }
   *out = x.release();
   return ACCG_OK;
 }
@@ -75,7 +108,7 @@ extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
   accg_smem_index* x = b->idx;
   ACCG_HIP(hipSetDevice(x->ctx->device));
   SmemArgs a;
-  a.bwt = x->d_bwt; a.primary = x->primary;
+  a.bwt = x->d_bwt; a.primary = x->primary; a.compact = x->compact ? 1u : 0u;
   for (int c = 0; c < 5; c++) a.L2[c] = x->L2[c];
   a.seq = b->d_seq; a.seq_len = b->d_len; a.seq_stride = b->stride; a.n_reads = b->n;
   a.out = b->d_out; a.mem_num = b->d_num; a.max_out = b->max_out; a.scratch = b->d_scratch; a.n_threads = b->slice;

@@ -25,6 +25,7 @@ constexpr int MIN_SEED_LEN = 19;   // smem/common/common.h:37
 struct Ctx {
   const uint32_t* bwt;
   uint64_t primary, L2[5];
+  bool compact;
 };
 
 // number of symbols equal to c among the first `upto + 1` symbols (0-based, MSB first) of the eight words of a block
@@ -45,10 +46,35 @@ __device__ __forceinline__ void count_block(const uint4 w0, const uint4 w1, int 
   cnt[1] += c1; cnt[2] += c2; cnt[3] += c3; cnt[0] += total - c1 - c2 - c3;
 }
 
+// the same over the four words of a compact block (64 symbols)
+__device__ __forceinline__ void count_half(const uint4 w4, int upto, uint64_t cnt[4]) {
+  const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+  const int wi = upto >> 4, r = upto & 15;
+  uint32_t c1 = 0, c2 = 0, c3 = 0, total = (uint32_t)upto + 1;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t keep = j < wi ? 0xFFFFFFFFu : j == wi ? (0xFFFFFFFFu << ((15 - r) << 1)) : 0u;
+    const uint32_t v = w[j];
+    const uint32_t lo = v & 0x55555555u, hi = (v >> 1) & 0x55555555u;
+    keep &= 0x55555555u;
+    c1 += __popc(lo & ~hi & keep);
+    c2 += __popc(hi & ~lo & keep);
+    c3 += __popc(hi & lo & keep);
+  }
+  cnt[1] += c1; cnt[2] += c2; cnt[3] += c3; cnt[0] += total - c1 - c2 - c3;
+}
+
 // bwt_occ4 (baseline.cpp:17-38)
 __device__ __forceinline__ void occ4(const Ctx& f, uint64_t k, uint64_t cnt[4]) {
   if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
   k -= (k >= f.primary);
+  if (f.compact) {       // wave-uniform: one 32-byte sector per lookup, two loads, four words to count
+    const uint4* blk = reinterpret_cast<const uint4*>(f.bwt + ((k >> 6) << 3));
+    const uint4 h = blk[0], w = blk[1];
+    cnt[0] = h.x; cnt[1] = h.y; cnt[2] = h.z; cnt[3] = h.w;
+    count_half(w, (int)(k & 63), cnt);
+    return;
+  }
   const uint4* blk = reinterpret_cast<const uint4*>(f.bwt + ((k >> 7) << 4));
   const uint4 h0 = blk[0], h1 = blk[1], w0 = blk[2], w1 = blk[3];
   cnt[0] = ((uint64_t)h0.y << 32) | h0.x; cnt[1] = ((uint64_t)h0.w << 32) | h0.z;
@@ -56,12 +82,28 @@ __device__ __forceinline__ void occ4(const Ctx& f, uint64_t k, uint64_t cnt[4]) 
   count_block(w0, w1, (int)(k & 127), cnt);
 }
 
+// bwt_2occ4 (baseline.cpp:40-85): Occ at k and at l; when both fall into one block (the usual case once the interval is
+// narrower than a block) the block is fetched once.  Lanes that do need a second block fetch it under EXEC.
+__device__ __forceinline__ void occ4_2(const Ctx& f, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4]) {
+  if (!f.compact || k == (uint64_t)-1 || l == (uint64_t)-1) { occ4(f, k, tk); occ4(f, l, tl); return; }
+  k -= (k >= f.primary); l -= (l >= f.primary);
+  const uint4* bk = reinterpret_cast<const uint4*>(f.bwt + ((k >> 6) << 3));
+  uint4 h = bk[0], w = bk[1];
+  tk[0] = h.x; tk[1] = h.y; tk[2] = h.z; tk[3] = h.w;
+  count_half(w, (int)(k & 63), tk);
+  if ((k >> 6) != (l >> 6)) {
+    const uint4* bl = reinterpret_cast<const uint4*>(f.bwt + ((l >> 6) << 3));
+    h = bl[0]; w = bl[1];
+  }
+  tl[0] = h.x; tl[1] = h.y; tl[2] = h.z; tl[3] = h.w;
+  count_half(w, (int)(l & 63), tl);
+}
+
 // bwt_extend (baseline.cpp:87-100); x[is_back ? 0 : 1] is the strand that is looked up
 __device__ __forceinline__ void extend(const Ctx& f, const SmemIntv& ik, SmemIntv ok[4], bool is_back) {
   uint64_t tk[4], tl[4];
   const uint64_t look = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
-  occ4(f, look - 1, tk);
-  occ4(f, look - 1 + ik.x2, tl);
+  occ4_2(f, look - 1, look - 1 + ik.x2, tk, tl);
   uint64_t lk[4], sz[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) { lk[c] = f.L2[c] + 1 + tk[c]; sz[c] = tl[c] - tk[c]; }
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(64, SMEM_MIN_WAVES) void smem_kernel(SmemArgs a, ui
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;
-  Ctx f; f.bwt = a.bwt; f.primary = a.primary;
+  Ctx f; f.bwt = a.bwt; f.primary = a.primary; f.compact = a.compact != 0;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = a.L2[c];
   const uint8_t* q = a.seq + (size_t)rd * a.seq_stride;
@@ -231,7 +273,7 @@ __global__ __launch_bounds__(64) void smem_kernel_fsm(SmemArgs a, uint32_t read_
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = tid < n_reads;
   const uint32_t rd = read_base + (live ? tid : 0);
-  Ctx f; f.bwt = a.bwt; f.primary = a.primary;
+  Ctx f; f.bwt = a.bwt; f.primary = a.primary; f.compact = a.compact != 0;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = a.L2[c];
   const uint8_t* q = a.seq + (size_t)rd * a.seq_stride;
