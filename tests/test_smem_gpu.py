@@ -43,8 +43,12 @@ def _oracle(bwt, para, seq, ln, max_out):
     return out, num
 
 
-@pytest.mark.parametrize("seed,glen,repeat", [(11, 4000, False), (12, 30000, True), (13, 200000, True)])
-def test_bit_exact_vs_oracle(ctx, seed, glen, repeat):
+@pytest.mark.parametrize("seed,glen,repeat,layout", [(11, 4000, False, "compact"), (12, 30000, True, "compact"), (13, 200000, True, "compact"),
+                                                      (12, 30000, True, "bwa"), (14, 100000, True, "bwa")])
+def test_bit_exact_vs_oracle(ctx, seed, glen, repeat, layout, monkeypatch):
+    """Both index layouts in HBM: the half-block re-layout done on upload (default) and BWA's own blocks."""
+    if layout == "bwa":
+        monkeypatch.setenv("ACCG_SMEM_COMPACT", "0")
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, size=glen).astype(np.uint8)
     if repeat:
