@@ -70,3 +70,25 @@ def test_compat_library_exports_reference_names():
                  "SWPairwiseAlignmentMultiBatch(", "serialize(void*, read_t const*, int)", "deserialize(void const*, hap_t*&)",
                  "free_reads(", "cleanup()", "ocl_init(", "smem_ocl(", "PairHMM::prepare()", "PairHMM::compute()", " create", " destroy"):
         assert name in syms, name
+
+
+def test_entry_points_refuse_a_null_context():
+    """Without a context (no gfx950 device) every compute entry point reports ACCG_ERR_NOT_INITIALISED (-2) -- none of them
+    falls back to host code."""
+    import ctypes as C
+    L = A.load()
+    vp = C.c_void_p
+    out = vp()
+    n = C.c_int64()
+    buf = (C.c_uint8 * 64)()
+    calls = [
+        lambda: L.accg_phmm_batch_create(None, 0, None, None, None, None, C.byref(out)),
+        lambda: L.accg_phmm_region(None, buf, 4, buf, 4, 0, None, None, None),
+        lambda: L.accg_phmm_region_f64(None, buf, 4, buf, 4, None),
+        lambda: L.accg_sw_batch_create(None, 0, None, 0, None, None, 0, None, None, 200, -150, -260, -11, C.byref(out)),
+        lambda: L.accg_smem_index_create(None, buf, 16, buf, C.byref(out)),
+        lambda: L.accg_bwasw_batch_create(None, 0, None, None, None, C.byref(out)),
+        lambda: L.accg_bwasw_records(None, buf, 0, buf, 1, None, 0, C.byref(n)),
+    ]
+    for k, call in enumerate(calls):
+        assert call() == -2, k
