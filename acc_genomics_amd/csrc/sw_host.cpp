@@ -42,9 +42,8 @@ struct accg_sw_batch {
   unsigned long long *d_cig_start = nullptr, *d_cig_total = nullptr;
   int max_el = 0;
   ~accg_sw_batch() {            // also reached on the error paths of accg_sw_batch_create
-    for (void* p : {(void*)d_refs, (void*)d_alts, (void*)d_strat, (void*)d_rl, (void*)d_al, (void*)d_score, (void*)d_p1, (void*)d_p2,
-                    (void*)d_work, (void*)d_bt, (void*)d_cig_n, (void*)d_cig_off, (void*)d_cig_el, (void*)d_cig_packed,
-                    (void*)d_cig_start, (void*)d_cig_total})
+    for (void* p : {(void*)d_refs, (void*)d_alts, (void*)d_strat, (void*)d_rl, (void*)d_al, (void*)d_score,
+                    (void*)d_work, (void*)d_bt, (void*)d_cig_total, (void*)d_cig_el, (void*)d_cig_packed})
       if (p) ctx->pool.put(p);
   }
 };
@@ -126,9 +125,9 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   if ((st = dev_upload(ctx, &b->d_al, alt_lens, sizeof(int32_t) * n, s)) != ACCG_OK) return st;
   if ((st = dev_upload(ctx, &b->d_strat, strat.data(), n, s)) != ACCG_OK) return st;
   if ((st = dev_upload(ctx, &b->d_work, work.data(), sizeof(SwWork) * work.size(), s)) != ACCG_OK) return st;
-  if ((st = dev_alloc(ctx, &b->d_score, sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
-  if ((st = dev_alloc(ctx, &b->d_p1, sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
-  if ((st = dev_alloc(ctx, &b->d_p2, sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
+  // score | p1 | p2 in one block: one copy brings all three back
+  if ((st = dev_alloc(ctx, &b->d_score, 3 * sizeof(int32_t) * std::max(n, 1))) != ACCG_OK) return st;
+  b->d_p1 = b->d_score + std::max(n, 1); b->d_p2 = b->d_p1 + std::max(n, 1);
   ACCG_HIP(hipStreamSynchronize(s));
   SwArgs& a = b->args;
   a.refs = b->d_refs; a.alts = b->d_alts; a.ref_stride = (uint32_t)ref_stride; a.alt_stride = (uint32_t)alt_stride;
@@ -164,10 +163,13 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
     if (b->d_cig_packed) { b->ctx->pool.put(b->d_cig_packed); b->d_cig_packed = nullptr; }
     { int st_ = dev_alloc(b->ctx, &b->d_cig_el, n1 * max_el * 2 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
     { int st_ = dev_alloc(b->ctx, &b->d_cig_packed, n1 * max_el * 2 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
-    if (!b->d_cig_start) { int st_ = dev_alloc(b->ctx, &b->d_cig_start, n1 * sizeof(unsigned long long)); if (st_ != ACCG_OK) return st_; }
-    if (!b->d_cig_total) { int st_ = dev_alloc(b->ctx, &b->d_cig_total, sizeof(unsigned long long)); if (st_ != ACCG_OK) return st_; }
-    if (!b->d_cig_n) { int st_ = dev_alloc(b->ctx, &b->d_cig_n, n1 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
-    if (!b->d_cig_off) { int st_ = dev_alloc(b->ctx, &b->d_cig_off, n1 * sizeof(int32_t)); if (st_ != ACCG_OK) return st_; }
+    if (!b->d_cig_total) {     // [total u64][start u64 x n][n_el i32 x n][offset i32 x n]: the per-pair results come back in one copy
+      int st_ = dev_alloc(b->ctx, &b->d_cig_total, (1 + n1) * sizeof(unsigned long long) + 2 * n1 * sizeof(int32_t));
+      if (st_ != ACCG_OK) return st_;
+      b->d_cig_start = b->d_cig_total + 1;
+      b->d_cig_n = reinterpret_cast<int32_t*>(b->d_cig_start + n1);
+      b->d_cig_off = b->d_cig_n + n1;
+    }
     b->max_el = max_el;
   }
   uint64_t limit = 16ull << 30;
@@ -211,13 +213,20 @@ extern "C" int accg_sw_batch_cigars_packed(accg_sw_batch* b, int32_t* n_el, int3
   ACCG_HIP(hipSetDevice(b->ctx->device));
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   const size_t n = (size_t)b->n;
-  unsigned long long tot = 0;
-  ACCG_HIP(hipMemcpy(&tot, b->d_cig_total, sizeof tot, hipMemcpyDeviceToHost));
+  const size_t n1 = std::max<size_t>(n, 1);
+  const size_t meta = (1 + n1) * sizeof(unsigned long long) + 2 * n1 * sizeof(int32_t);
+  void* stage = nullptr;
+  ACCG_HIP(ctx_stage(b->ctx, meta, &stage));
+  ACCG_HIP(hipMemcpyAsync(stage, b->d_cig_total, meta, hipMemcpyDeviceToHost, b->ctx->stream));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  const unsigned long long* m64 = (const unsigned long long*)stage;
+  const int32_t* m32 = (const int32_t*)(m64 + 1 + n1);
+  const unsigned long long tot = m64[0];
   if (total) *total = tot;
   if (n) {
-    if (n_el) ACCG_HIP(hipMemcpy(n_el, b->d_cig_n, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (offsets) ACCG_HIP(hipMemcpy(offsets, b->d_cig_off, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (starts) ACCG_HIP(hipMemcpy(starts, b->d_cig_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (n_el) memcpy(n_el, m32, n * sizeof(int32_t));
+    if (offsets) memcpy(offsets, m32 + n1, n * sizeof(int32_t));
+    if (starts) memcpy(starts, m64 + 1, n * sizeof(uint64_t));
   }
   if (elements) {
     if (capacity < tot) return ACCG_ERR_BAD_ARG;      // *total says how much is needed
@@ -269,9 +278,14 @@ extern "C" int accg_sw_batch_results(accg_sw_batch* b, int32_t* score, int32_t* 
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   const size_t bytes = sizeof(int32_t) * (size_t)b->n;
   if (bytes) {
-    if (score) ACCG_HIP(hipMemcpy(score, b->d_score, bytes, hipMemcpyDeviceToHost));
-    if (p1) ACCG_HIP(hipMemcpy(p1, b->d_p1, bytes, hipMemcpyDeviceToHost));
-    if (p2) ACCG_HIP(hipMemcpy(p2, b->d_p2, bytes, hipMemcpyDeviceToHost));
+    void* stage = nullptr;
+    ACCG_HIP(ctx_stage(b->ctx, 3 * bytes, &stage));
+    ACCG_HIP(hipMemcpyAsync(stage, b->d_score, 3 * bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+    const int32_t* r = (const int32_t*)stage;
+    if (score) memcpy(score, r, bytes);
+    if (p1) memcpy(p1, r + b->n, bytes);
+    if (p2) memcpy(p2, r + 2 * (size_t)b->n, bytes);
   }
   return ACCG_OK;
 }

@@ -337,20 +337,63 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   // (when the bottom-row scan picked j == altLen the segment is 0 as well)
   if (seg > 0 && strat == 0) { push(seg, 4); seg = 0; }                               // soft clip, :2342-2345
   int state = 0;
+  // The walk is a chain of dependent loads (the next cell is known only from this cell's bits).  Nearly every step is
+  // diagonal, so the record entries of the next eight diagonal cells -- and, inside a gap, of the next eight cells along the
+  // gap -- are fetched together and then examined in order: one memory latency per eight cells instead of one per cell.
+  constexpr int LOOK = 8;
+  auto entry = [&](int i, int j, int& shift) -> const uint4* {
+    const int sidx = LANE_IS_ALT ? i : j, pos = LANE_IS_ALT ? j : i;
+    const int flat = pos - 1 + pad, l = flat / K, k = flat - l * K;
+    shift = K - 1 - k + 16 * half;
+    return bt + (uint64_t)(sidx + l) * LPP + l;
+  };
   do {
-    int ns_ = 0, step = 1;
-    if (bit(p1, p2, 2)) {                       // not diagonal
-      if (bit(p1, p2, 3)) {                     // down: deletion of kd rows
-        ns_ = 2;
-        int r = p1;
-        while (r > 1 && !bit(r, p2, P_VOPEN)) { step++; r--; }   // row 1 always opens (its extension source is -inf); the bound is a guard
-      } else {                                  // right: insertion of ki columns
-        ns_ = 1;
-        int c = p2;
-        while (c > 1 && !bit(p1, c, P_HOPEN)) { step++; c--; }
-      }
+    // ---- run of diagonal cells starting at (p1, p2)
+    uint4 e[LOOK]; int sh[LOOK];
+    const int nv = min(LOOK, min(p1, p2));
+#pragma unroll
+    for (int d = 0; d < LOOK; d++) {
+      sh[d] = 0; e[d] = make_uint4(0, 0, 0, 0);
+      if (d < nv) e[d] = *entry(p1 - d, p2 - d, sh[d]);
     }
-    if (ns_ == 0) { p1--; p2--; } else if (ns_ == 1) p2 -= step; else p1 -= step;
+    int d = 0;
+#pragma unroll
+    for (int q = 0; q < LOOK; q++)
+      if (d == q && q < nv && !((e[q].z >> sh[q]) & 1u)) d = q + 1;        // cell q is diagonal: pass it
+    if (d > 0) {
+      if (state == 0) seg += d; else { push(seg, state); seg = d; state = 0; }
+      p1 -= d; p2 -= d;
+    }
+    if (d == nv) continue;                    // window used up (or the border reached) without meeting a gap
+    // ---- (p1, p2) is not diagonal; its entry is e[d]
+    uint4 ce = e[0]; int cs = sh[0];
+#pragma unroll
+    for (int q = 1; q < LOOK; q++) if (d == q) { ce = e[q]; cs = sh[q]; }
+    const bool down = (ce.w >> cs) & 1u;      // down: deletion of kd rows; else right: insertion of ki columns
+    const int ns_ = down ? 2 : 1;
+    int step = 1;
+    // run length = 1 + number of leading cells (from this one, walking back) that did not open the gap; the cell at
+    // index 1 always opens (its extension source is -inf), the bound is a guard
+    int r = down ? p1 : p2;
+    bool open_found = false;
+    while (!open_found && r > 1) {
+      uint4 ge[LOOK]; int gs[LOOK];
+      const int gn = min(LOOK, r - 1);
+#pragma unroll
+      for (int q = 0; q < LOOK; q++) {
+        gs[q] = 0; ge[q] = make_uint4(0, 0, 0, 0);
+        if (q < gn) ge[q] = down ? *entry(r - q, p2, gs[q]) : *entry(p1, r - q, gs[q]);
+      }
+      int t = 0;
+#pragma unroll
+      for (int q = 0; q < LOOK; q++) {
+        const unsigned w = (down ? (P_VOPEN == 0 ? ge[q].x : ge[q].y) : (P_HOPEN == 0 ? ge[q].x : ge[q].y));
+        if (t == q && q < gn) { if ((w >> gs[q]) & 1u) open_found = true; else t = q + 1; }
+      }
+      step += t; r -= t;
+      if (t < gn) open_found = true;
+    }
+    if (ns_ == 1) p2 -= step; else p1 -= step;
     if (ns_ == state) seg += step;
     else { push(seg, state); seg = step; state = ns_; }
   } while (p1 > 0 && p2 > 0);
