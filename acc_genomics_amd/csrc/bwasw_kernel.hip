@@ -16,7 +16,6 @@
 namespace accg {
 namespace {
 
-constexpr int NEGV = -(1 << 28);
 typedef short s2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL>

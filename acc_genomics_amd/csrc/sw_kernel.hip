@@ -315,13 +315,6 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   const int nl = LANE_IS_ALT ? altLen : refLen;
   const int pad = LPP * K - nl;
   const uint4* bt = a.bt + (uint64_t)(work_base + wi - bt_first) * a.bt_item_stride + (uint64_t)g * (sweep_cap + LPP) * LPP;
-  // plane p of cell (i, j) (1-based reference coordinates)
-  auto bit = [&](int i, int j, int plane) -> unsigned {
-    const int sidx = LANE_IS_ALT ? i : j, pos = LANE_IS_ALT ? j : i;
-    const int flat = pos - 1 + pad, l = flat / K, k = flat - l * K;
-    const unsigned* w = reinterpret_cast<const unsigned*>(bt + (uint64_t)(sidx + l) * LPP + l);
-    return (w[plane] >> (K - 1 - k + 16 * half)) & 1u;
-  };
   // planes: 0 lane-direction gap opened, 1 sweep-direction gap opened; "right" (insertion) runs along the alternate
   const int P_HOPEN = LANE_IS_ALT ? 0 : 1, P_VOPEN = LANE_IS_ALT ? 1 : 0;
   int p1 = a.p1[pair], p2 = a.p2[pair];
