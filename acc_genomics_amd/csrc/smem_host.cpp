@@ -86,13 +86,18 @@ extern "C" int accg_smem_batch_create(accg_smem_index* idx, const uint8_t* seq, 
   ACCG_HIP(hipSetDevice(idx->ctx->device));
   std::unique_ptr<accg_smem_batch> b(new accg_smem_batch);
   b->idx = idx; b->n = n_reads; b->stride = seq_stride; b->max_out = max_out;
-  b->slice = std::min<uint32_t>(std::max<uint32_t>(n_reads, 64), 262144);   // 512 x 32 B of scratch per resident read
+  // Reads of one launch: each holds 512 interval records of scratch (16 B with 32-bit bounds, 32 B otherwise), i.e. 8.6 GB
+  // for 2^20 reads -- small change out of 288 GB, and one big launch beats several smaller ones (every launch ends in a tail
+  // of the few wavefronts whose reads took longest: 21.5 ms in four launches, 17.5 ms in one, for 2^20 reads).
+  uint32_t max_slice = idx->compact ? (1u << 20) : (1u << 19);
+  if (const char* e = getenv("ACCG_SMEM_SLICE")) max_slice = std::max<uint32_t>(64, (uint32_t)strtoul(e, nullptr, 10));
+  b->slice = std::min<uint32_t>(std::max<uint32_t>(n_reads, 64), max_slice);
   const size_t n1 = std::max<uint32_t>(n_reads, 1);
   ACCG_HIP(hipMalloc((void**)&b->d_seq, n1 * seq_stride));
   ACCG_HIP(hipMalloc((void**)&b->d_len, n1));
   ACCG_HIP(hipMalloc((void**)&b->d_out, n1 * max_out * sizeof(SmemIntv)));
   ACCG_HIP(hipMalloc((void**)&b->d_num, n1 * sizeof(int32_t)));
-  ACCG_HIP(hipMalloc((void**)&b->d_scratch, (size_t)b->slice * 512 * sizeof(SmemIntv)));
+  ACCG_HIP(hipMalloc((void**)&b->d_scratch, (size_t)b->slice * 512 * (idx->compact ? 16 : sizeof(SmemIntv))));
   if (n_reads) {
     ACCG_HIP(hipMemcpy(b->d_seq, seq, (size_t)n_reads * seq_stride, hipMemcpyHostToDevice));
     ACCG_HIP(hipMemcpy(b->d_len, seq_len, n_reads, hipMemcpyHostToDevice));
