@@ -240,8 +240,11 @@ __device__ int seed_strategy1(const Ctx<IT>& f, int len, const uint8_t* q, int x
   return len;
 }
 
+#ifndef SMEM_WAVES_PER_EU
+#define SMEM_WAVES_PER_EU 5     // what the allocator reaches on its own (95 VGPRs); see DESIGN.md 4b for 6 and 8
+#endif
 template <typename IT>
-__global__ __launch_bounds__(64) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_PER_EU))) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libaccg_hip.so")
+    return os.environ.get("ACCG_LIB_OVERRIDE") or os.path.join(_HERE, "libaccg_hip.so")
 
 
 class AccgError(RuntimeError):
