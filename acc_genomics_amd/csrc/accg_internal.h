@@ -66,8 +66,8 @@ struct accg_ctx {
   // Independent kernels of one pass (one launch per rows-per-lane class) are spread over these streams, forked from and
   // joined back to `stream`: queued on one stream each launch would wait for the previous one's last wavefront.
   static constexpr int N_AUX = 4;
-  hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t aux[N_AUX] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {};
 };
 
 namespace accg {
