@@ -19,8 +19,11 @@ struct SmemArgs {
   uint32_t max_out;
   SmemIntv* scratch;            // 2 x 256 intervals per thread, interleaved: element e of thread t at [e * n_threads + t]
   uint32_t n_threads;
+  uint32_t* queue;              // engine variant: next read of the launch (zeroed before it)
 };
 
 hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s);
+// persistent wavefronts that take reads from a queue; compact (32-bit) index only; scratch for n_waves x 64 threads
+hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s);
 
 }  // namespace accg

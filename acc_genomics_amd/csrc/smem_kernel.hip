@@ -271,11 +271,216 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_P
   a.mem_num[rd] = mem.n;
 }
 
+
+// ---- engine variant (32-bit intervals only) ----------------------------------------------------------------------------
+// In the kernel above the 64 reads of a wavefront share one program counter: a read that leaves a loop early idles until the
+// slowest one is through, and bwt_extend -- the only expensive step -- runs with 14 of 64 lanes on average
+// (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).  The table itself can serve 2.6x the lookups that kernel asks for
+// (tools/ubench_random.hip: 180 G random sectors/s out of a 64 MB table with full wavefronts).  Here every lane is a small
+// state machine over the same functions: each round all lanes that want a bwt_extend get it together (full wavefront, 64
+// lookups in flight per instruction), then each lane consumes its result and, in the common case (it stays inside the loop it
+// is in), posts its next request at once; only lanes that leave a loop go through the general transition switch.  Lanes that
+// finish their read take the next one from a queue, so a wavefront never waits for its slowest read.
+// MEASURED (configs[4]): bit-exact, VALU lanes 21 of 64 instead of 14, the same fabric traffic -- but 27.7 ms against 17.5 ms:
+// the transition code reads the curr / back lists from the HBM scratch with dependent loads, and that latency now stalls
+// the whole wavefront every few rounds instead of one subset of lanes.  Kept selectable (ACCG_SMEM_ENGINE=1) and under test
+// as the starting point for a version with the lists' hot entries in LDS; the default is the plain kernel above.
+enum : int {
+  E_FETCH, P1_NEXT, A_INIT, A_FWD_RES, A_BACK_INIT, A_ITER, A_BK_RES, A_BK_DONE, A_FE_K, A_FE_RES, A_POST, A_RETURN, P2_NEXT,
+  P3_NEXT, P3_RES, E_DONE
+};
+
+#ifndef SMEM_SLOW_BATCH
+#define SMEM_SLOW_BATCH 12
+#endif
+__global__ __launch_bounds__(64) void smem_engine(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+  typedef uint32_t IT;
+  typedef Intv<IT> I;
+  constexpr int SLOW_BATCH = SMEM_SLOW_BATCH;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
+  Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads;
+  // the lane's current read, 4 bits per base, in LDS (row of 128 B per lane, rows 132 B apart to spread the banks): the
+  // state machine looks at a base of the read in almost every transition
+  __shared__ uint32_t s_read[64 * 33];
+  uint32_t* my_read = s_read + threadIdx.x * 33;
+  struct ReadView {
+    const uint32_t* w;
+    __device__ __forceinline__ int operator[](int i) const { return (int)((w[i >> 3] >> ((i & 7) << 2)) & 0xFu); }
+  } q{my_read};
+  int len = 0;
+  uint32_t rd = 0;
+  Out mem; mem.a = a.out; mem.cap = a.max_out; mem.n = 0;
+
+  int st = E_FETCH, pass = 1;
+  int x = 0, i = 0, i2 = 0, kk = 0, m = 0, k2 = 0, old_n = 0, min_intv = 1, ret = 0;
+  int n_curr = 0, n_back = 0, start = 0, stop = 0, max_len = 0;
+  I ik, temp, ci, nx;
+  ik.x0 = ik.x1 = ik.x2 = 0; ik.set(0, 0); temp = ik; ci = ik; nx = ik;
+  bool req = false, req_back = false;
+  int req_c = 0;
+
+  // forward step of bwt_smem1a_new's first loop (:199-216) at position i: request, or close the list and go backwards
+  auto fwd_step = [&]() {
+    if (i < len && q[i] < 4) { req = true; req_back = false; req_c = 3 - q[i]; st = A_FWD_RES; }
+    else { L.curr(n_curr++) = ik; st = A_BACK_INIT; }
+  };
+  auto bk_step = [&]() {                                   // "backenlarge" loop head (:224-241)
+    if (kk < 0 || q[kk] >= 4) st = A_BK_DONE;
+    else { req = true; req_back = true; req_c = q[kk]; st = A_BK_RES; }
+  };
+  auto p3_step = [&]() {                                   // bwt_seed_strategy1 loop head (:312-325)
+    if (i >= len) { x = len; st = P3_NEXT; }
+    else if (q[i] >= 4) { x = i + 1; st = P3_NEXT; }
+    else { req = true; req_back = false; req_c = 3 - q[i]; st = P3_RES; }
+  };
+
+  for (;;) {
+    // ---- transitions of the lanes that are between two loops ------------------------------------------------------------
+    // Run them in batches: a lane between two loops waits (without a request) until SLOW_BATCH lanes are in that position or
+    // nobody has a request left -- the transition code is executed by the whole wavefront whoever needs it.
+    const unsigned long long slow = __ballot(!req && st != E_DONE);
+    if (__popcll(slow) >= SLOW_BATCH || !__any(req))
+    while (__any(!req && st != E_DONE)) {
+      if (!req && st != E_DONE) {
+        switch (st) {
+          case E_FETCH: {                                       // next read of the launch
+            const uint32_t r = atomicAdd(a.queue, 1u);
+            if (r >= n_reads) { st = E_DONE; break; }
+            rd = read_base + r;
+            len = a.seq_len[rd];
+            {
+              const uint8_t* src = a.seq + (size_t)rd * a.seq_stride;
+              for (int w8 = 0; w8 * 8 < len; w8++) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                  const int pos = w8 * 8 + e;
+                  const uint32_t c = pos < len ? src[pos] : 4u;
+                  packed |= (c > 4u ? 4u : c) << (e << 2);
+                }
+                my_read[w8] = packed;
+              }
+            }
+            mem.a = a.out + (size_t)rd * a.max_out; mem.n = 0;
+            x = 0; pass = 1; st = P1_NEXT;
+          } break;
+          case P1_NEXT:                                         // mem_collect_intv_new, first pass (:394-400)
+            while (x < len && q[x] >= 4) x++;
+            if (x >= len) { old_n = mem.n < (int)mem.cap ? mem.n : (int)mem.cap; k2 = 0; pass = 2; st = P2_NEXT; }
+            else { min_intv = 1; st = A_INIT; }
+            break;
+          case P2_NEXT: {                                       // second pass (:403-408)
+            bool go = false;
+            while (k2 < old_n && !go) {
+              const SmemIntv p = mem.a[k2++];
+              const int s0 = (int)(p.info >> 32), e0 = (int)(int32_t)p.info;
+              if (e0 - s0 < 28 || p.x2 > 10) continue;
+              x = (s0 + e0) >> 1; min_intv = (int)p.x2 + 1; go = true;
+            }
+            if (go) st = (q[x] > 3) ? P2_NEXT : A_INIT;
+            else { x = 0; pass = 3; st = P3_NEXT; }
+          } break;
+          case A_INIT:                                          // bwt_smem1a_new prologue (:193-197)
+            if (min_intv < 1) min_intv = 1;
+            ik = set_intv1(f, q[x]); ik.set((uint32_t)(x + 1), 0);
+            n_curr = 0; n_back = 0; i = x + 1; temp.x0 = temp.x1 = temp.x2 = 0; temp.set(0, 0);
+            fwd_step();
+            break;
+          case A_BACK_INIT:
+            ret = (int)L.curr(n_curr - 1).lo();
+            start = x; stop = x; max_len = 0; i2 = 0;
+            st = A_ITER;
+            break;
+          case A_ITER:                                          // :220-299
+            if (i2 >= n_curr) { st = A_RETURN; break; }
+            ci = L.curr(i2);
+            ik = ci; ik.set(ci.lo(), ci.hi() | (uint32_t)x);
+            if (n_back == 0 || stop - start >= 3) { n_back = 0; L.back(n_back++) = ik; kk = x - 1; bk_step(); }
+            else { stop = (int)ci.lo(); kk = n_back - 1; st = A_FE_K; }
+            break;
+          case A_BK_DONE:
+            start = (int)ci.lo();
+            stop = (i2 == n_curr - 1) ? len : (int)L.curr(i2 + 1).lo();
+            if (i2 != 0 && ik.hi() > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
+            temp = ik;
+            st = A_POST;
+            break;
+          case A_FE_K:                                          // "forwardenlarge" (:255-281)
+            if (kk < 0) { st = A_POST; break; }
+            ik = L.back(kk); m = start + 1;
+            if (m > stop) { kk--; break; }                      // empty inner loop: nothing reached, next k
+            req = true; req_back = false; req_c = 3 - q[m - 1]; st = A_FE_RES;
+            break;
+          case A_POST:                                          // :283-298
+            i2++;
+            if (i2 < n_curr) max_len = (int)temp.hi() + (int)L.curr(i2).lo();
+            while (max_len < MIN_SEED_LEN && i2 < n_curr) {
+              i2++;
+              if (i2 < n_curr) stop = (int)L.curr(i2).lo();
+              max_len = (int)temp.hi() + stop;
+            }
+            if (i2 >= n_curr && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
+            st = A_ITER;
+            break;
+          case A_RETURN:
+            if (pass == 1) { x = ret; st = P1_NEXT; } else st = P2_NEXT;
+            break;
+          case P3_NEXT:                                         // third pass (:411-419) + bwt_seed_strategy1 (:306-327)
+            while (x < len && q[x] >= 4) x++;
+            if (x >= len) { a.mem_num[rd] = mem.n; st = E_FETCH; }
+            else { ik = set_intv1(f, q[x]); i = x + 1; p3_step(); }
+            break;
+          default: st = E_DONE; break;
+        }
+      }
+    }
+    if (!__any(req)) break;                                     // every lane is done and the queue is empty
+    // ---- one bwt_extend for every lane that asked ------------------------------------------------------------------------
+    if (req) {
+      nx = extend(f, ik, req_back, req_c);
+      req = false;
+      // ---- consume the result; staying inside the same loop posts the next request right away ---------------------------
+      if (st == A_FWD_RES) {
+        bool stop_now = false;
+        if (nx.x2 != ik.x2) { L.curr(n_curr++) = ik; stop_now = nx.x2 < (IT)min_intv; }
+        if (stop_now) st = A_BACK_INIT;
+        else { ik = nx; ik.set((uint32_t)(i + 1), 0); i++; fwd_step(); }
+      } else if (st == A_BK_RES) {
+        if (nx.x2 < (IT)min_intv) st = A_BK_DONE;
+        else { ik = nx; ik.set(ci.lo(), ci.hi() | (uint32_t)kk); L.back(n_back++) = ik; kk--; bk_step(); }
+      } else if (st == A_FE_RES) {
+        if (nx.x2 < (IT)min_intv) { kk--; st = A_FE_K; }
+        else {
+          ik = nx;
+          if (m == stop) {
+            ik.set(ci.lo(), ci.hi() | (uint32_t)(x - kk));
+            if ((uint32_t)(x - kk) > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
+            temp = ik;
+            st = A_POST;
+          } else { m++; req = true; req_back = false; req_c = 3 - q[m - 1]; }
+        }
+      } else {   // P3_RES
+        if (nx.x2 < 20 && i - x >= MIN_SEED_LEN) {
+          I mm = nx; mm.set((uint32_t)(i + 1), (uint32_t)x);
+          if (mm.x2 > 0) mem.push(mm);
+          x = i + 1; st = P3_NEXT;
+        } else { ik = nx; i++; p3_step(); }
+      }
+    }
+  }
+}
+
 }  // namespace
 
-// (A lock-step variant -- every read an explicit state machine, the wavefront executing one bwt_extend per round together --
-// was built and measured in this round: 35 % slower, because serialising the per-lane control flow costs more than the
-// divergent bwt_extend it removes; see DESIGN.md section 4b.  It is not kept in the tree.)
+hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s) {
+  if (n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(smem_engine, dim3(n_waves), dim3(64), 0, s, a, read_base, n_reads);
+  return hipGetLastError();
+}
+
 hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
   if (a.compact) hipLaunchKernelGGL(smem_kernel<uint32_t>, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, read_base, n_reads);
