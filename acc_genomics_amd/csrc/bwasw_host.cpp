@@ -52,30 +52,39 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
     if (blob_bytes > 0xFFFFFFF0ull) return ACCG_ERR_TOO_LONG;
     b->cells += (uint64_t)p[0] * p[1] + (uint64_t)p[2] * p[3];
   }
-  std::vector<uint8_t> blob(blob_bytes + 16, 4);
-  for (uint32_t i = 0; i < n_seeds; i++) {
+  // the blob is assembled straight in the context's pinned staging (all host threads), then goes over in one copy
+  const size_t blob_size = blob_bytes + 16;
+  void* stage_v = nullptr;
+  ACCG_HIP(ctx_stage(ctx, blob_size, &stage_v));
+  uint8_t* blob = (uint8_t*)stage_v;
+#pragma omp parallel for schedule(static, 1024) num_threads(accg::host_threads())
+  for (int64_t i = 0; i < (int64_t)n_seeds; i++) {
     const BwaswSeed& s = seeds[i];
     const uint8_t* src = seqs + seq_off[i];           // [left query][right query][left target][right target]
     const uint32_t len[4] = {s.qlen[0], s.qlen[1], s.tlen[0], s.tlen[1]};
     const uint32_t dst[4] = {s.q_off[0], s.q_off[1], s.t_off[0], s.t_off[1]};
+    const uint32_t nxt = i + 1 < (int64_t)n_seeds ? seeds[i + 1].q_off[0] : (uint32_t)blob_size;
     for (int part = 0; part < 4; part++) {
-      for (uint32_t k = 0; k < len[part]; k++) { const uint8_t c = src[k]; blob[dst[part] + k] = c > 3 ? 4 : c; }
+      uint8_t* d = blob + dst[part];
+      for (uint32_t k = 0; k < len[part]; k++) { const uint8_t c = src[k]; d[k] = c > 3 ? 4 : c; }
+      const uint32_t end = part < 3 ? dst[part + 1] : nxt;      // alignment padding reads as N
+      for (uint32_t k = dst[part] + len[part]; k < end; k++) blob[k] = 4;
       src += len[part];
     }
   }
   // one side of four seeds per wavefront: same K, similar target lengths (a wavefront runs as long as its longest member);
-  // every left pass is queued before the right passes that read its records
+  // every left pass is queued before the right passes that read its records.  Order = (K descending, tlen descending, index
+  // ascending): a counting sort on the 16-bit key, stable in the index.
   std::vector<BwaswWork> work;
-  std::vector<uint32_t> order(n_seeds);
+  work.reserve((size_t)n_seeds / 2 + 64);
+  std::vector<uint32_t> order(n_seeds), bucket(17u * 2048u + 1u);
   for (int side = 0; side < 2; side++) {
     auto kclass = [&](uint32_t x) { return (seeds[x].qlen[side] + 1 + 15) / 16; };
-    std::iota(order.begin(), order.end(), 0u);
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-      const int kx = kclass(x), ky = kclass(y);
-      if (kx != ky) return kx > ky;
-      if (seeds[x].tlen[side] != seeds[y].tlen[side]) return seeds[x].tlen[side] > seeds[y].tlen[side];
-      return x < y;
-    });
+    auto key = [&](uint32_t x) { return (uint32_t)(16 - kclass(x)) * 2048u + (2047u - seeds[x].tlen[side]); };   // ascending key
+    std::fill(bucket.begin(), bucket.end(), 0u);
+    for (uint32_t x = 0; x < n_seeds; x++) bucket[key(x) + 1]++;
+    for (size_t k = 1; k < bucket.size(); k++) bucket[k] += bucket[k - 1];
+    for (uint32_t x = 0; x < n_seeds; x++) order[bucket[key(x)]++] = x;
     for (uint32_t i = 0; i < n_seeds;) {
       const int K = kclass(order[i]);
       accg_bwasw_batch::Launch L{K, side, (uint32_t)work.size(), 0};
@@ -88,15 +97,17 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
       b->launches.push_back(L);
     }
   }
-  ACCG_HIP(ctx->pool.get(blob.size(), (void**)&b->d_blob));
+  hipStream_t st = ctx->stream;
+  ACCG_HIP(ctx->pool.get(blob_size, (void**)&b->d_blob));
   ACCG_HIP(ctx->pool.get(std::max<size_t>(n_seeds, 1) * sizeof(BwaswSeed), (void**)&b->d_seeds));
   ACCG_HIP(ctx->pool.get(std::max<size_t>(work.size(), 1) * sizeof(BwaswWork), (void**)&b->d_work));
   ACCG_HIP(ctx->pool.get(std::max<size_t>(n_seeds, 1) * 8 * sizeof(int16_t), (void**)&b->d_out));
-  ACCG_HIP(hipMemcpy(b->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  ACCG_HIP(hipMemcpyAsync(b->d_blob, blob, blob_size, hipMemcpyHostToDevice, st));
   if (n_seeds) {
-    ACCG_HIP(hipMemcpy(b->d_seeds, seeds.data(), n_seeds * sizeof(BwaswSeed), hipMemcpyHostToDevice));
-    ACCG_HIP(hipMemcpy(b->d_work, work.data(), work.size() * sizeof(BwaswWork), hipMemcpyHostToDevice));
+    ACCG_HIP(hipMemcpyAsync(b->d_seeds, seeds.data(), n_seeds * sizeof(BwaswSeed), hipMemcpyHostToDevice, st));
+    ACCG_HIP(hipMemcpyAsync(b->d_work, work.data(), work.size() * sizeof(BwaswWork), hipMemcpyHostToDevice, st));
   }
+  ACCG_HIP(hipStreamSynchronize(st));                // the staging and the vectors go away / get reused
   *out = b.release();
   return ACCG_OK;
 }
