@@ -46,6 +46,7 @@ def load():
     L.accg_stream.argtypes = [vp]
     L.accg_device_name.argtypes = [vp, C.c_char_p, sz]
     L.accg_phmm_region.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp, C.POINTER(Counters)]
+    L.accg_phmm_region_f64.argtypes = [vp, vp, sz, vp, sz, vp]
     L.accg_phmm_batch_create.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
     for n in ("accg_phmm_batch_pairs", "accg_phmm_batch_cells", "accg_phmm_batch_algorithmic_bytes", "accg_phmm_batch_jobs"):
         getattr(L, n).restype = C.c_uint64
@@ -133,6 +134,17 @@ class Context:
         _check(self.L.accg_phmm_region(self.h, rb, len(rb), hb, len(hb), mode, raw.ctypes.data,
                                        l10.ctypes.data if want_log10 else None, C.byref(cnt)))
         return raw, l10, cnt
+
+
+def _phmm_region_f64(self, reads_ser, haps_ser, n_pairs):
+    """accg_phmm_region_f64: every pair in fp64 (the reference's use_double path) -> raw float64[n_pairs] (x 2^1020)."""
+    out = np.zeros(n_pairs, np.float64)
+    rb, hb = bytes(reads_ser), bytes(haps_ser)
+    _check(self.L.accg_phmm_region_f64(self.h, rb, len(rb), hb, len(hb), out.ctypes.data))
+    return out
+
+
+Context.phmm_region_f64 = _phmm_region_f64
 
 
 class PhmmBatch:

@@ -196,3 +196,21 @@ def test_mixed_length_regions_concurrent_classes(ctx):
         assert np.max(np.abs(l10f[off:off + n] - ol10) / np.abs(ol10)) < REL_TOL
         off += n; resc += r
     assert cnt.rescued == resc and resc > 0
+
+
+def test_fp64_rescue_near_the_double_denormal_range(ctx):
+    """Long unrelated reads: the fp64 rescue pass itself works near 2.2e-308 (likelihood x 2^1020 around 1e-295), where x86's
+    MXCSR.FTZ -- on in the reference (FalconPairHMM.cpp:850) -- flushes double results too.  The device code is built with fp64
+    denormals flushed for that reason; found by tools/fuzz_phmm.py."""
+    rng = synth.rng_for(304)
+    reads, haps = synth.make_region(rng, 12, 6, (600, 760), (1000, 2200), unrelated_frac=1.0)
+    rs, hs = synth.serialize_reads(reads), synth.serialize_haps(haps)
+    raw, l10, cnt = ctx.phmm_region(rs, hs, 72, A.ACCG_PHMM_STRICT)
+    oraw, ol10, resc = _oracle_region(reads, haps)
+    assert cnt.rescued == resc == 72
+    assert ol10.min() < -590                      # fp64 values x 2^1020 below 1e-283: states of the sweep dip into denormals
+    assert raw.tobytes() == oraw.tobytes() and l10.tobytes() == ol10.tobytes()
+    f64 = ctx.phmm_region_f64(rs, hs, 72)
+    O = orc.oracle()
+    want = np.array([O.orc_phmm_forward_f64(*orc.pair_args(r, h), 0) for r in reads for h in haps])
+    assert f64.tobytes() == want.tobytes()

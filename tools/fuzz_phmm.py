@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Randomised PairHMM parity run (GPU strict mode vs the oracle, bit for bit): random region shapes, read lengths 1..1023,
+haplotype lengths 1..4000, N bases, extreme qualities.  usage: tools/fuzz_phmm.py [n_regions] [seed]"""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import acc_genomics_amd as A
+from acc_genomics_amd import synth
+import orc
+
+n_regions = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+O = orc.oracle()
+bad = 0
+with A.Context(0) as ctx:
+    for it in range(n_regions):
+        kind = rng.integers(0, 4)
+        if kind == 0: rl = (1, int(rng.integers(1, 40))); hl = (1, int(rng.integers(1, 60)))
+        elif kind == 1: rl = (int(rng.integers(20, 150)), int(rng.integers(150, 260))); hl = (int(rng.integers(1, 300)), int(rng.integers(300, 600)))
+        elif kind == 2: rl = (int(rng.integers(250, 600)), int(rng.integers(600, 1024))); hl = (int(rng.integers(300, 1000)), int(rng.integers(1000, 2500)))
+        else: rl = (int(rng.integers(1, 130)), int(rng.integers(130, 131))); hl = (3000, 4000)
+        nr, nh = int(rng.integers(1, 24)), int(rng.integers(1, 9))
+        reads, haps = synth.make_region(rng, nr, nh, rl, hl, n_frac=float(rng.choice([0, 0.01, 0.2])), unrelated_frac=float(rng.choice([0, 0.3, 1.0])))
+        if rng.random() < 0.3:        # extreme qualities
+            for r in reads:
+                n = len(r["b"])
+                for key in ("q", "i", "d", "c"):
+                    r[key] = rng.integers(0, 128, size=n).astype(np.uint8).tobytes() if rng.random() < 0.5 else r[key]
+        mode = A.ACCG_PHMM_STRICT
+        raw, l10, cnt = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), nr * nh, mode)
+        rl_, hl_, keep = orc.region_args(reads, haps)
+        oraw, ol10 = np.zeros(nr * nh, np.float32), np.zeros(nr * nh, np.float64)
+        resc = O.orc_phmm_region(nr, orc.ptr(rl_, orc.i32p), *keep[:5], nh, orc.ptr(hl_, orc.i32p), keep[5], orc.ptr(oraw, orc.f32p), orc.ptr(ol10, orc.f64p), 16)
+        ok = raw.tobytes() == oraw.tobytes() and l10.tobytes() == ol10.tobytes() and cnt.rescued == resc
+        if not ok:
+            bad += 1
+            print("MISMATCH region", it, "kind", kind, "reads", [len(r["b"]) for r in reads][:6], "haps", [len(h) for h in haps][:6], int((raw != oraw).sum()), int((l10 != ol10).sum()), cnt.rescued, resc)
+print("regions %d, mismatching %d" % (n_regions, bad))
