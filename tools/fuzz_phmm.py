@@ -13,6 +13,7 @@ n_regions = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 O = orc.oracle()
 bad = 0
+worst_fast = 0.0
 with A.Context(0) as ctx:
     for it in range(n_regions):
         kind = rng.integers(0, 4)
@@ -33,7 +34,13 @@ with A.Context(0) as ctx:
         oraw, ol10 = np.zeros(nr * nh, np.float32), np.zeros(nr * nh, np.float64)
         resc = O.orc_phmm_region(nr, orc.ptr(rl_, orc.i32p), *keep[:5], nh, orc.ptr(hl_, orc.i32p), keep[5], orc.ptr(oraw, orc.f32p), orc.ptr(ol10, orc.f64p), 16)
         ok = raw.tobytes() == oraw.tobytes() and l10.tobytes() == ol10.tobytes() and cnt.rescued == resc
+        fraw, fl10, fcnt = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), nr * nh, A.ACCG_PHMM_FAST)
+        fin = np.isfinite(ol10)                         # likelihood 0 even in fp64: log10 = -inf on both sides
+        if not np.array_equal(np.isfinite(fl10), fin): print("FAST MODE: -inf pattern differs, region", it); bad += 1
+        rel = float(np.max(np.abs(fl10[fin] - ol10[fin]) / np.abs(ol10[fin]))) if fin.any() else 0.0
+        worst_fast = max(worst_fast, rel)
+        if rel >= 1e-5: print("FAST MODE over tolerance: region", it, "kind", kind, rel); bad += 1
         if not ok:
             bad += 1
             print("MISMATCH region", it, "kind", kind, "reads", [len(r["b"]) for r in reads][:6], "haps", [len(h) for h in haps][:6], int((raw != oraw).sum()), int((l10 != ol10).sum()), cnt.rescued, resc)
-print("regions %d, mismatching %d" % (n_regions, bad))
+print("regions %d, mismatching %d, fast mode worst relative error on log10 %.2e (bar 1e-5)" % (n_regions, bad, worst_fast))
