@@ -66,15 +66,25 @@ struct PhmmArgs {
 // ---- fp64 rescue planning (device side, no host round trip) -----------------------------------------
 // Reads that underflowed in fp32 against at least one haplotype are regrouped into new wavefront jobs so that
 // the fp64 pass only carries those reads (FalconPairHMM.cpp:636-652 redoes exactly the underflowed pairs).
-constexpr int PHMM_RESCUE_CLASSES = 6;    // (lanes per read, K): (16,4) (16,8) (16,12) (16,16) (32,16) (64,16)
+// (lanes per read, K) of the fp64 rescue kernels: 16 lanes x K for K in the list below, then (32,16) and (64,16).  Fine steps in K
+// matter here: an fp64 row costs twice the registers and ~1.8x the issue time of an fp32 one, so rows of padding are expensive.
+constexpr int PHMM_RESCUE_K16 = 11;
+constexpr int PHMM_RESCUE_CLASSES = PHMM_RESCUE_K16 + 2;
+__host__ __device__ inline int phmm_rescue_k16(int i) {
+  constexpr int ks[PHMM_RESCUE_K16] = {2, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16};
+  return ks[i];
+}
+__host__ __device__ inline void phmm_rescue_shape(int cls, int* lpp, int* K) {
+  if (cls < PHMM_RESCUE_K16) { *lpp = 16; *K = phmm_rescue_k16(cls); }
+  else { *lpp = cls == PHMM_RESCUE_K16 ? 32 : 64; *K = 16; }
+}
 __host__ __device__ inline void phmm_rescue_class(uint32_t len, int* cls, int* lpp, int* K) {
   const uint32_t rows = len + 1;
-  if (rows <= 64) { *cls = 0; *lpp = 16; *K = 4; }
-  else if (rows <= 128) { *cls = 1; *lpp = 16; *K = 8; }
-  else if (rows <= 192) { *cls = 2; *lpp = 16; *K = 12; }
-  else if (rows <= 256) { *cls = 3; *lpp = 16; *K = 16; }
-  else if (rows <= 512) { *cls = 4; *lpp = 32; *K = 16; }
-  else { *cls = 5; *lpp = 64; *K = 16; }
+  int c = PHMM_RESCUE_K16 + 1;
+  if (rows <= 256) { c = 0; while (16u * (uint32_t)phmm_rescue_k16(c) < rows) c++; }
+  else if (rows <= 512) c = PHMM_RESCUE_K16;
+  *cls = c;
+  phmm_rescue_shape(c, lpp, K);
 }
 struct PhmmRegionDev { uint32_t read0, n_reads, chunk0, n_chunks, n_haps, pad_; };
 struct PhmmChunkDev { uint32_t ids0, n; };

@@ -269,7 +269,7 @@ struct accg_phmm_batch {
   DevBuf<PhmmRegionDev> d_regions;
   DevBuf<PhmmChunkDev> d_chunks;
   DevBuf<uint32_t> d_sorted_reads, d_flagged;
-  DevBuf<uint32_t> d_state;   // zeroed per run: [n_reads] read flags, [6] rescue job counts, [2] n_rescued (u64)
+  DevBuf<uint32_t> d_state;   // zeroed per run: [n_reads] read flags, rescue job counts per class, [2] n_rescued (u64)
   DevBuf<PhmmWork> d_rescue_jobs;
   uint64_t last_kernel_ns = 0;
 };
@@ -500,7 +500,7 @@ void partition(accg_phmm_batch& b) {
 
 // layout of accg_phmm_batch::d_state (uint32 words)
 size_t state_counts(const accg_phmm_batch& b) { return (b.rd.size() + 1) / 2 * 2; }
-size_t state_nresc(const accg_phmm_batch& b) { return state_counts(b) + 8; }
+size_t state_nresc(const accg_phmm_batch& b) { return state_counts(b) + (PHMM_RESCUE_CLASSES + 3) / 2 * 2; }
 size_t state_words(const accg_phmm_batch& b) { return state_nresc(b) + 2; }
 
 template <typename T>
@@ -538,7 +538,6 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   a.work = b->d_rescue_jobs.p;
   a.stream_cap = b->rescue_stream_cap; a.haps_cap = b->rescue_haps_cap;
-  static const int cls_lpp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 32, 64}, cls_k[PHMM_RESCUE_CLASSES] = {4, 8, 12, 16, 16, 16};
   int n_cls = 0;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) n_cls += b->rescue_bound[c] != 0;
   const bool fork = n_cls > 1;
@@ -549,7 +548,9 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     if (!bound) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
-    ACCG_HIP(phmm_launch_rescue_f64(cls_k[c], cls_lpp[c], mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, st));
+    int lpp_c, k_c;
+    phmm_rescue_shape(c, &lpp_c, &k_c);
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
