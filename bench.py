@@ -307,8 +307,8 @@ def bench_bwasw(ctx, rank, dist, torch, steps, with_cpu, n_seeds=1 << 18):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sw-steps", type=int, default=5, help="passes over the Smith-Waterman batch (0 = skip that leg)")
