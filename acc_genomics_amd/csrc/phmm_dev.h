@@ -114,5 +114,6 @@ hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, const PhmmArgs<do
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
 hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 constexpr float PHMM_MIN_ACCEPTED = 1e-28f;   // host_type.h:21
+constexpr int PHMM_RESCUE_GRID = 4096;        // wavefronts per rescue launch (they stride over the device-side job count)
 
 }  // namespace accg

@@ -136,12 +136,10 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
 template <typename T, int K, int LPP, bool STRICT, bool RESCUE>
-__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
+__device__ __forceinline__ void phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr unsigned SLAB = QT * 1024;                 // bytes between two bases' tables
-  const uint32_t job = blockIdx.x;
-  if (RESCUE && a.job_count && job >= *a.job_count) return;   // the grid is a host-side upper bound
   unsigned char* tab = smem;
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
   uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
@@ -321,10 +319,27 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   }
 }
 
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE>
+__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
+  if (RESCUE && a.job_count) {
+    // the number of jobs is only known on the device (phmm_rescue_plan); the grid is capped on the host and every wavefront
+    // walks the job array with the grid's stride, so a class with nothing to do costs a few hundred empty wavefronts instead
+    // of one per potential job
+    const uint32_t n = __builtin_amdgcn_readfirstlane(*a.job_count);
+    for (uint32_t job = blockIdx.x; job < n; job += gridDim.x) {
+      phmm_job<T, K, LPP, STRICT, RESCUE>(a, work_base, job);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next job rebuilds the LDS tables this one still read
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    phmm_job<T, K, LPP, STRICT, RESCUE>(a, work_base, blockIdx.x);
+  }
+}
+
 template <typename T, bool STRICT, bool RESCUE>
 hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
   if (n_work == 0) return hipSuccess;
-  dim3 grid(n_work), block(64);
+  dim3 grid(RESCUE && a.job_count ? (n_work < PHMM_RESCUE_GRID ? n_work : (uint32_t)PHMM_RESCUE_GRID) : n_work), block(64);
 #define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
     const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL);             \
