@@ -523,7 +523,12 @@ int launch_f32(accg_phmm_batch* b, int mode) {
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : b->ctx->stream;
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, mode == ACCG_PHMM_STRICT, a, l.work0, l.n_work, st));
+    // reads longer than 255 bases (32 / 64 lanes) always take the reference's operation order: over some 10^6 cells per pair
+    // the contracted form drifts to 5e-6 on log10 against a 1e-5 bar (tools/fuzz_phmm.py), and such reads are rare enough
+    // (nothing in the BASELINE configs) for the 12-op column not to matter
+    // ... and so do reads of at most 15 bases: their log10 is close to 0, where the reference's float `log10f(x) - log10f(2^120)`
+    // has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show as more than 1e-5 relative
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, mode == ACCG_PHMM_STRICT || l.lpp >= 32 || l.lpp * l.K <= 16, a, l.work0, l.n_work, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -550,7 +555,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
     phmm_rescue_shape(c, &lpp_c, &k_c);
-    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, st));
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, a, (uint32_t)c * b->rescue_cap, bound, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;

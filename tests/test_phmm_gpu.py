@@ -214,3 +214,19 @@ def test_fp64_rescue_near_the_double_denormal_range(ctx):
     O = orc.oracle()
     want = np.array([O.orc_phmm_forward_f64(*orc.pair_args(r, h), 0) for r in reads for h in haps])
     assert f64.tobytes() == want.tobytes()
+    # the fp64 rescue keeps the reference's operation order behind the fast fp32 pass too: near the denormal range a contracted
+    # form lands up to 2.6e-5 away (which values get flushed depends on the last bits of every intermediate)
+    _, fl10, fcnt = ctx.phmm_region(rs, hs, 72, A.ACCG_PHMM_FAST)
+    assert fcnt.rescued == 72 and fl10.tobytes() == ol10.tobytes()
+
+
+def test_fast_mode_takes_the_reference_order_where_contraction_is_not_safe(ctx):
+    """Reads of at most 15 bases (log10 close to 0: the reference's float log10 subtraction has a granularity of 3.8e-6 there)
+    and reads longer than 255 bases run the strict column in fast mode too: bit-equal results."""
+    rng = synth.rng_for(305)
+    for rl, hl in (((1, 15), (1, 60)), ((300, 700), (400, 900))):
+        reads, haps = synth.make_region(rng, 16, 6, rl, hl)
+        rs, hs = synth.serialize_reads(reads), synth.serialize_haps(haps)
+        sraw, sl10, _ = ctx.phmm_region(rs, hs, 96, A.ACCG_PHMM_STRICT)
+        fraw, fl10, _ = ctx.phmm_region(rs, hs, 96, A.ACCG_PHMM_FAST)
+        assert fraw.tobytes() == sraw.tobytes() and fl10.tobytes() == sl10.tobytes()

@@ -14,6 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 O = orc.oracle()
 bad = 0
 worst_fast = 0.0
+worst_info = None
 with A.Context(0) as ctx:
     for it in range(n_regions):
         kind = rng.integers(0, 4)
@@ -38,9 +39,13 @@ with A.Context(0) as ctx:
         fin = np.isfinite(ol10)                         # likelihood 0 even in fp64: log10 = -inf on both sides
         if not np.array_equal(np.isfinite(fl10), fin): print("FAST MODE: -inf pattern differs, region", it); bad += 1
         rel = float(np.max(np.abs(fl10[fin] - ol10[fin]) / np.abs(ol10[fin]))) if fin.any() else 0.0
+        if rel > worst_fast:
+            kw = int(np.argmax(np.where(fin, np.abs(fl10 - ol10) / np.abs(ol10), 0)))
+            worst_info = (it, int(kind), len(reads[kw // nh]["b"]), len(haps[kw % nh]), float(ol10[kw]), float(fl10[kw]), float(oraw[kw]), float(fraw[kw]))
         worst_fast = max(worst_fast, rel)
         if rel >= 1e-5: print("FAST MODE over tolerance: region", it, "kind", kind, rel); bad += 1
         if not ok:
             bad += 1
             print("MISMATCH region", it, "kind", kind, "reads", [len(r["b"]) for r in reads][:6], "haps", [len(h) for h in haps][:6], int((raw != oraw).sum()), int((l10 != ol10).sum()), cnt.rescued, resc)
+print("worst fast-mode pair (region, kind, read len, hap len, log10 oracle, log10 fast, raw oracle, raw fast):", worst_info)
 print("regions %d, mismatching %d, fast mode worst relative error on log10 %.2e (bar 1e-5)" % (n_regions, bad, worst_fast))
