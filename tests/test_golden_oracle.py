@@ -48,10 +48,16 @@ def test_phmm_golden(path):
     assert l10.tobytes() == g["log10_scalar_nofma"].tobytes()
     assert resc == int(g["rescued_scalar_nofma"])
     # and inside the 1e-5 budget of the judged path (computePairhmmAVX as the reference builds it)
-    rel = np.abs(l10 - g["log10_avx"]) / np.abs(g["log10_avx"])
-    assert rel.max() < 2e-6
+    fin = np.isfinite(g["log10_avx"])              # likelihood 0 even in fp64: -inf on both sides
+    assert np.array_equal(np.isfinite(l10), fin)
+    # Within ~1e18 of the smallest normal double the reference's own builds disagree (x86 FTZ decides by the last bits of every
+    # intermediate which values are flushed; phmm_near_denormal holds a pair where -mfma moves compute_fp_avxd by 1.5e-4):
+    # those pairs are pinned by the bit-exact comparison above only.
+    fin &= (g["raw_f64_avx"] > 1e-290) | (g["raw_avx"] >= 1e-28)
+    rel = np.abs(l10[fin] - g["log10_avx"][fin]) / np.abs(g["log10_avx"][fin])
+    assert rel.size == 0 or rel.max() < 2e-6
     ok = g["raw_avx"] > 1e-28
-    assert (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < 1e-5
+    assert not ok.any() or (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < 1e-5
 
 
 @pytest.mark.parametrize("path", SW, ids=[os.path.basename(p)[:-4] for p in SW])

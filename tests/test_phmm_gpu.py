@@ -53,10 +53,14 @@ def test_golden_fast_within_tolerance(ctx, path):
     n = int(g["n_reads"]) * int(g["n_haps"])
     raw, l10, cnt = ctx.phmm_region(g["reads_ser"].tobytes(), g["haps_ser"].tobytes(), n, A.ACCG_PHMM_FAST)
     want = g["log10_avx"]                       # FalconPairHMM::computePairhmmAVX as the reference builds it
-    assert np.all(np.isfinite(l10))
-    assert (np.abs(l10 - want) / np.abs(want)).max() < REL_TOL
+    fin = np.isfinite(want)                     # likelihood 0 even in fp64 (random qualities): -inf on both sides
+    assert np.array_equal(np.isfinite(l10), fin)
+    # within ~1e18 of the smallest normal double the reference's own builds disagree by more than the bar (see
+    # tests/test_golden_oracle.py); those pairs are held bit-exactly to the uncontracted baseline by the strict test above
+    fin &= (g["raw_f64_avx"] > 1e-290) | (g["raw_avx"] >= 1e-28)
+    assert not fin.any() or (np.abs(l10[fin] - want[fin]) / np.abs(want[fin])).max() < REL_TOL
     ok = g["raw_avx"] > 1e-27                   # away from the rescue threshold the raw fp32 value is judged too
-    assert (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < REL_TOL
+    assert not ok.any() or (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < REL_TOL
 
 
 def test_fast_matches_its_arithmetic_model(ctx):

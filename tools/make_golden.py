@@ -112,6 +112,17 @@ def main():
     rng = synth.rng_for(5)   # tiny and long edge shapes
     phmm_fixture("phmm_edges", *synth.make_region(rng, 10, 6, (1, 33), (1, 40), unrelated_frac=0.2))
     phmm_fixture("phmm_long", *synth.make_region(rng, 4, 3, (180, 256), (800, 1024), unrelated_frac=0.5))
+    # the regimes in which the randomised parity runs (tools/fuzz_phmm.py) found deviations of an earlier fast mode
+    rng = synth.rng_for(6)
+    phmm_fixture("phmm_tiny", *synth.make_region(rng, 40, 6, (1, 15), (1, 60), unrelated_frac=0.1))          # log10 close to 0
+    phmm_fixture("phmm_near_denormal", *synth.make_region(rng, 10, 5, (600, 760), (1000, 2200), unrelated_frac=1.0))   # fp64 x 2^1020 ~ 1e-300
+    phmm_fixture("phmm_very_long", *synth.make_region(rng, 6, 3, (700, 1023), (1200, 2000)))                  # 10^6 cells per pair in fp32
+    reads, haps = synth.make_region(rng, 20, 6, (30, 200), (100, 400), n_frac=0.02, unrelated_frac=0.2)
+    for r in reads:                                                                                            # every quality value
+        n = len(r["b"])
+        for key in ("q", "i", "d", "c"):
+            r[key] = rng.integers(0, 128, size=n).astype(np.uint8).tobytes()
+    phmm_fixture("phmm_any_quality", reads, haps)
     rng = synth.rng_for(2)   # C2 shape: 300-bp window vs 150-bp read
     sw_fixture("sw_c2_slice", *synth.make_sw_pairs(rng, 64, 300, 150))
     sw_fixture("sw_small", *synth.make_sw_pairs(rng, 32, 41, 37))
