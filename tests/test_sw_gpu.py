@@ -176,7 +176,7 @@ def test_golden_cigars(ctx, path):
     rl, al = np.full(n, refs.shape[1], np.int32), np.full(n, alts.shape[1], np.int32)
     for s in range(4):
         with A.SwBatch(ctx, refs, rl, alts, al, strategies=s) as b:
-            b.run_cigar(64)
+            b.run_cigar(int(g["cig_len"].shape[2]))
             n_el, off, el = b.cigars()
             sc, p1, p2 = b.results()
         assert np.array_equal(sc, g["score"][s]) and np.array_equal(p1, g["p1"][s]) and np.array_equal(p2, g["p2"][s])

@@ -44,10 +44,9 @@ def phmm_fixture(name, reads, haps):
     print(name, "pairs", n, "rescued", int(res["rescued_avx"]))
 
 
-def sw_fixture(name, refs, alts):
+def sw_fixture(name, refs, alts, MAXE=64):
     R = orc.ref_sw()
     n, rl, al = refs.shape[0], refs.shape[1], alts.shape[1]
-    MAXE = 64
     out = {k: np.zeros((4, n), np.int32) for k in ("score", "p1", "p2", "offset", "n_el")}
     cl = np.zeros((4, n, MAXE), np.int32)
     cs = np.zeros((4, n, MAXE), np.int32)
@@ -127,6 +126,11 @@ def main():
     sw_fixture("sw_c2_slice", *synth.make_sw_pairs(rng, 64, 300, 150))
     sw_fixture("sw_small", *synth.make_sw_pairs(rng, 32, 41, 37))
     sw_fixture("sw_wide", *synth.make_sw_pairs(rng, 16, 120, 200))
+    sw_fixture("sw_long", *synth.make_sw_pairs(rng, 3, 1300, 700, sub_rate=0.05, indel_rate=0.004), MAXE=256)   # 32 / 64 lanes, int32 arithmetic
+    bases = np.frombuffer(b"ACGT", np.uint8)                                                                  # ties everywhere
+    lo_r = bases[rng.integers(0, 2, size=(24, 70))]; lo_a = bases[rng.integers(0, 2, size=(24, 55))]
+    lo_r[:4] = ord("A"); lo_a[:2] = ord("A"); lo_a[2:4] = ord("C")
+    sw_fixture("sw_low_complexity", lo_r, lo_a, MAXE=128)
 
 
 if __name__ == "__main__":
