@@ -73,9 +73,13 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
     // highest: nl matches; lowest: a border prefill of ns gaps plus nl mismatches plus one more open.
     const long hi = (long)std::max(w_match, 0) * nl;
     const long lo = (long)std::min(w_open, 0) * 2 + (long)std::min(w_extend, 0) * ns + (long)std::min(w_mismatch, 0) * nl;
-    const bool p16 = hi <= 32000 && lo >= -32000 && std::abs(w_match) < 16000 && std::abs(w_mismatch) < 16000;
     const int lpp = nl <= 255 ? 16 : nl <= 511 ? 32 : 64;
-    items[k] = {(uint32_t)k, sw_pick_k(nl, lpp), lpp, ns, p16, lia};
+    const int Kk = sw_pick_k(nl, lpp);
+    // ... and only up to 16 positions per lane: the decision record keeps one bit per position in each 16-bit half of its planes
+    // (K = 20 / 24 exist for sequences over 1024 on 64 lanes; with small-magnitude weights those used to pass the range test, and
+    // their CIGARs came out wrong while score and end cell were right -- found by tools/fuzz_sw.py)
+    const bool p16 = hi <= 32000 && lo >= -32000 && std::abs(w_match) < 16000 && std::abs(w_mismatch) < 16000 && Kk <= 16;
+    items[k] = {(uint32_t)k, Kk, lpp, ns, p16, lia};
     b->cells += (uint64_t)rl * al;
     b->algo_bytes += (uint64_t)rl + al + 16;
   }

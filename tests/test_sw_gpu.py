@@ -273,3 +273,24 @@ def test_packed_cigars_agree_with_slots(ctx):
         if pn[k] > 0:
             assert np.array_equal(pel[int(starts[k]):int(starts[k]) + pn[k]], el[k, :pn[k]]), k
             assert np.array_equal(pel2[int(starts2[k]):int(starts2[k]) + pn[k]], el[k, :pn[k]]), k
+
+
+def test_long_pairs_with_small_weights_cigars(ctx):
+    """Sequences over 1024 on 64 lanes need K = 20 / 24 positions per lane; with small-magnitude weights their values would fit
+    16 bits, but the decision record has 16 bits per half-plane, so these classes must run in 32 bits (they once did not: right
+    scores, wrong CIGARs -- found by tools/fuzz_sw.py)."""
+    rng = synth.rng_for(540)
+    n = 10
+    refs, rl, alts, al = _ragged(rng, n, 1050, 1500, 1050, 1500)
+    strat = rng.integers(0, 4, size=n).astype(np.uint8)
+    w = (10, -8, -30, -2)
+    with A.SwBatch(ctx, refs, rl, alts, al, strategies=strat, weights=w) as b:
+        b.run_cigar(3100)
+        n_el, off, el = b.cigars()
+        sc, p1, p2 = b.results()
+    O = orc.oracle()
+    for k in range(n):
+        wsc, wp1, wp2, woff, wcig, wn = orc.sw_pair(O, refs[k, :rl[k]].tobytes(), alts[k, :al[k]].tobytes(), int(strat[k]), w, max_el=4096)
+        assert (sc[k], p1[k], p2[k], n_el[k]) == (wsc, wp1, wp2, wn), k
+        if wn > 0:
+            assert off[k] == woff and list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig, k

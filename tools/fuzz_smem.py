@@ -40,7 +40,12 @@ for it in range(rounds):
         os.environ.update(env)
         with A.Context(0) as ctx, A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, max_out) as b:
             b.run(); got, gnum = b.results()
-        ok = np.array_equal(gnum, wnum) and all(np.array_equal(got[k, :min(gnum[k], max_out)], want[k, :min(wnum[k], max_out)]) for k in range(n))
+        # a count above max_out only says "does not fit, redo" (smem/main.cpp:159-164): the kernel re-seeds from the stored SMEMs
+        # only, so beyond that point the two counts need not be the same number -- both must be above max_out, and the stored
+        # entries equal
+        fits = wnum <= max_out
+        ok = np.array_equal(gnum[fits], wnum[fits]) and bool((gnum[~fits] > max_out).all())
+        ok = ok and all(np.array_equal(got[k, :min(gnum[k], max_out)], want[k, :min(wnum[k], max_out)]) for k in range(n))
         total += 1
         if not ok:
             bad += 1; print("MISMATCH round", it, "genome", glen, kind, "max_out", max_out, env)
