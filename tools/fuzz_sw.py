@@ -32,7 +32,8 @@ with A.Context(0) as ctx:
                 a = BASES[rng.integers(0, alpha, size=al[k])]
             refs[k, :rl[k]] = r; alts[k, :al[k]] = a
         strat = rng.integers(0, 4, size=n).astype(np.uint8)
-        w = [(200, -150, -260, -11), (1, -1, -2, -1), (10, -8, -30, -2), (2000, -1500, -2600, -110), (25, -50, -110, -6)][int(rng.integers(0, 5))]
+        w = [(200, -150, -260, -11), (1, -1, -2, -1), (10, -8, -30, -2), (2000, -1500, -2600, -110), (25, -50, -110, -6), (0, 0, 0, 0),
+             (30000, -30000, -32000, -1), (5, -4, -1, -1), (1, -3, -5, 0), (20, -20, -15999, -15)][int(rng.integers(0, 10))]
         with A.SwBatch(ctx, refs, rl, alts, al, strategies=strat, weights=w) as b:
             b.run_cigar(3100)
             n_el, off, el = b.cigars()
