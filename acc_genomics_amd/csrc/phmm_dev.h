@@ -109,8 +109,10 @@ void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);
 hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 // fp64 rescue pass: same jobs as the fp32 pass; a wavefront redoes only the haplotypes for which one of
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.
-// always in the operation order of compute_full_prob_baseline<double> (bit-exact with it), also behind the fast fp32 pass
-hipError_t phmm_launch_rescue_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+// strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in
+// that order of every job that produced a result below PHMM_F64_TINY
+hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+constexpr double PHMM_F64_TINY = 1e-280;      // x 2^1020 scaling included: 28 decades above the smallest normal double
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
 hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 constexpr float PHMM_MIN_ACCEPTED = 1e-28f;   // host_type.h:21

@@ -555,7 +555,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
     phmm_rescue_shape(c, &lpp_c, &k_c);
-    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, a, (uint32_t)c * b->rescue_cap, bound, st));
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;

@@ -218,10 +218,16 @@ def test_fp64_rescue_near_the_double_denormal_range(ctx):
     O = orc.oracle()
     want = np.array([O.orc_phmm_forward_f64(*orc.pair_args(r, h), 0) for r in reads for h in haps])
     assert f64.tobytes() == want.tobytes()
-    # the fp64 rescue keeps the reference's operation order behind the fast fp32 pass too: near the denormal range a contracted
-    # form lands up to 2.6e-5 away (which values get flushed depends on the last bits of every intermediate)
+    # behind the fast fp32 pass the rescue uses the contracted column, but a job that produces a result below 1e-280 (x 2^1020;
+    # log10 below about -587) is redone in the reference's order: near the denormal range a contracted result lands up to
+    # 2.6e-5 away, because which values get flushed depends on the last bits of every intermediate
     _, fl10, fcnt = ctx.phmm_region(rs, hs, 72, A.ACCG_PHMM_FAST)
-    assert fcnt.rescued == 72 and fl10.tobytes() == ol10.tobytes()
+    assert fcnt.rescued == 72
+    fin = np.isfinite(ol10)
+    assert np.array_equal(np.isfinite(fl10), fin)
+    assert (np.abs(fl10[fin] - ol10[fin]) / np.abs(ol10[fin])).max() < 1e-7
+    deep = fin & (ol10 < -600)
+    assert deep.any() and fl10[deep].tobytes() == ol10[deep].tobytes()
 
 
 def test_fast_mode_takes_the_reference_order_where_contraction_is_not_safe(ctx):
