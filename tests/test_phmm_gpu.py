@@ -232,9 +232,9 @@ def test_fp64_rescue_near_the_double_denormal_range(ctx):
 
 def test_fast_mode_takes_the_reference_order_where_contraction_is_not_safe(ctx):
     """Reads of at most 15 bases (log10 close to 0: the reference's float log10 subtraction has a granularity of 3.8e-6 there)
-    and reads longer than 255 bases run the strict column in fast mode too: bit-equal results."""
+    run the strict column in fast mode too: bit-equal results."""
     rng = synth.rng_for(305)
-    for rl, hl in (((1, 15), (1, 60)), ((300, 700), (400, 900))):
+    for rl, hl in (((1, 15), (1, 60)),):
         reads, haps = synth.make_region(rng, 16, 6, rl, hl)
         rs, hs = synth.serialize_reads(reads), synth.serialize_haps(haps)
         sraw, sl10, _ = ctx.phmm_region(rs, hs, 96, A.ACCG_PHMM_STRICT)
