@@ -240,3 +240,32 @@ def test_fast_mode_takes_the_reference_order_where_contraction_is_not_safe(ctx):
         sraw, sl10, _ = ctx.phmm_region(rs, hs, 96, A.ACCG_PHMM_STRICT)
         fraw, fl10, _ = ctx.phmm_region(rs, hs, 96, A.ACCG_PHMM_FAST)
         assert fraw.tobytes() == sraw.tobytes() and fl10.tobytes() == sl10.tobytes()
+
+
+def test_one_context_per_thread_runs_concurrently():
+    """a context is single-threaded, concurrent callers take one context each (they share the
+    device).  Four threads, each with its own context, run different regions at the same time; results equal the oracle."""
+    import threading
+    rng = synth.rng_for(306)
+    jobs = []
+    for _ in range(4):
+        reads, haps = synth.make_region(rng, 24, 6, (40, 160), (100, 400), unrelated_frac=0.2)
+        oraw, ol10, _ = _oracle_region(reads, haps)
+        jobs.append((synth.serialize_reads(reads), synth.serialize_haps(haps), oraw, ol10))
+    errors = []
+
+    def work(k):
+        try:
+            rs, hs, oraw, ol10 = jobs[k]
+            with A.Context(0) as c:
+                for _ in range(60):
+                    raw, l10, _ = c.phmm_region(rs, hs, 24 * 6, A.ACCG_PHMM_STRICT)
+                    if raw.tobytes() != oraw.tobytes() or l10.tobytes() != ol10.tobytes():
+                        errors.append(k); return
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors
