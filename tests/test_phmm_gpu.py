@@ -269,3 +269,34 @@ def test_one_context_per_thread_runs_concurrently():
     for t in ts: t.start()
     for t in ts: t.join()
     assert not errors, errors
+
+
+def test_full_size_c3_properties(ctx):
+    """BASELINE configs[3] at full size (1024 regions x 128 reads of 70-151 bp x 16 haplotypes of 70-500 bp = 2 097 152 pairs,
+    1 % N, 10 % of the reads unrelated so that the fp64 rescue runs): idempotence of reruns, invariance under a permutation of
+    the regions, the rescued share, and a sampled comparison with the oracle."""
+    rng = synth.rng_for(3)
+    regs = []
+    for _ in range(1024):
+        rl = int(rng.integers(70, 152)); hl = int(rng.integers(max(70, rl), 501))
+        regs.append(synth.make_region(rng, 128, 16, rl, hl, n_frac=0.01, unrelated_frac=0.10))
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]
+    with A.PhmmBatch(ctx, ser) as b:
+        assert b.pairs == 1024 * 128 * 16
+        b.run(A.ACCG_PHMM_FAST)
+        raw1, l1, c1 = b.results()
+        b.run(A.ACCG_PHMM_FAST)
+        raw2, l2, c2 = b.results()
+    assert raw1.tobytes() == raw2.tobytes() and l1.tobytes() == l2.tobytes() and c1.rescued == c2.rescued
+    assert 0.05 < c1.rescued / b.pairs < 0.2
+    perm = rng.permutation(1024)
+    with A.PhmmBatch(ctx, [ser[i] for i in perm]) as b:
+        b.run(A.ACCG_PHMM_FAST)
+        _, l3, c3 = b.results()
+    assert c3.rescued == c1.rescued
+    assert np.array_equal(l3.reshape(1024, 2048), l1.reshape(1024, 2048)[perm])
+    for ri in rng.choice(1024, 6, replace=False):
+        reads, haps = regs[ri]
+        _, ol10, _ = _oracle_region(reads, haps)
+        got = l1[ri * 2048:(ri + 1) * 2048]
+        assert np.max(np.abs(got - ol10) / np.abs(ol10)) < REL_TOL
