@@ -165,3 +165,22 @@ def test_fpga_record_stream(ctx):
     assert np.array_equal(f, want)
     with pytest.raises(AccgError):                              # a truncated stream is refused, not read past its end
         bwasw_records(ctx, np.array(stream[:len(stream) - 3], np.int64).astype(np.int32), pac)
+
+
+def test_full_size_properties(ctx):
+    """2^18 seeds from 150-bp reads (the shape bench.py measures): idempotence, the extension never lowers a seed's score, end
+    points inside their sequences, and 8192 seeds against the oracle."""
+    rng = np.random.default_rng(46)
+    n = 1 << 18
+    seqs, off, par = synth.make_bwasw_seeds(rng, n, read_len=150)
+    with BwaswBatch(ctx, seqs, off, par) as b:
+        b.run(); got, words = b.results()
+        b.run(); got2, _ = b.results()
+    assert np.array_equal(got, got2)
+    p = par.astype(np.int32)
+    assert (got[:, 5] >= p[:, 4]).all() and (got[:, 4] >= p[:, 4]).all()              # trueScore, score >= seed_len
+    assert (got[:, 0] >= 0).all() and (got[:, 0] <= p[:, 5]).all()                    # qBeg in [0, seed_qbeg]
+    assert (got[:, 1] >= 0).all() and (got[:, 1] <= p[:, 2]).all()                    # qEnd in [0, rightQlen]
+    assert (-got[:, 2] <= p[:, 1]).all() and (got[:, 3] <= p[:, 3]).all()             # rBeg, rEnd inside the targets
+    want = _oracle(seqs, off[:8192], par[:8192])
+    assert np.array_equal(got[:8192], want)

@@ -7,6 +7,9 @@ import orc
 import acc_genomics_amd as A
 from acc_genomics_amd import fmindex
 
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -92,3 +95,45 @@ def test_small_output_slot_counts_but_does_not_store(ctx):
     assert (gnum <= wnum).all() and (gnum >= np.minimum(wnum, 2)).all()
     for k in range(len(reads)):
         assert np.array_equal(got[k, :min(2, gnum[k])], want[k, :min(2, gnum[k])])
+
+
+def test_full_size_c4_properties(ctx, tmp_path):
+    """BASELINE configs[4] at full size (2^20 reads x 150 bp against the 64 MB index of a 67 108 864-bp genome): idempotence,
+    structural properties of every interval, the full-length seed of the exact reads, and 4096 reads against the oracle."""
+    import subprocess, sys
+    rng = np.random.default_rng(4)
+    G = 67108864
+    g = rng.integers(0, 4, size=G).astype(np.uint8)
+    # the suffix array of 1.3e8 symbols is built with torch on the GPU, in a child process: torch's bundled HIP runtime does not
+    # come up in a process in which libaccg_hip.so has already initialised the device
+    np.save(tmp_path / "g.npy", g)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from acc_genomics_amd import fmindex; "
+            "g = np.load(%r); bwt, para, _ = fmindex.build(g, device='cuda'); np.savez(%r, bwt=bwt, para=para)"
+            % (ROOT, str(tmp_path / "g.npy"), str(tmp_path / "idx.npz")))
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=600)
+    z = np.load(tmp_path / "idx.npz"); bwt, para = z["bwt"], z["para"]
+    n = 1 << 20
+    offs = rng.integers(0, G - 150, size=n)
+    reads = g[offs[:, None] + np.arange(150)[None, :]]
+    flip = rng.random(n) < 0.5
+    reads[flip] = 3 - reads[flip][:, ::-1]
+    exact = rng.random(n) < 0.25
+    m = (rng.random(reads.shape) < 0.01) & ~exact[:, None]
+    reads[m] = rng.integers(0, 4, size=int(m.sum()))
+    seq = np.zeros((n, 256), np.uint8); seq[:, :150] = reads
+    ln = np.full(n, 150, np.uint8)
+    with A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, 64) as b:
+        b.run(); got, num = b.results()
+        b.run(); got2, num2 = b.results()
+    assert np.array_equal(num, num2) and np.array_equal(got, got2)
+    assert num.max() <= 64 and num.min() >= 1
+    valid = np.arange(64)[None, :] < num[:, None]
+    start, end = (got[:, :, 3] >> np.uint64(32)).astype(np.int64), (got[:, :, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert ((end - start >= 19) | ~valid).all() and ((end <= 150) | ~valid).all() and ((got[:, :, 2] >= 1) | ~valid).all()
+    full = ((start == 0) & (end == 150) & valid).any(axis=1)
+    assert full[exact].all()                        # an error-free read has its whole length as an SMEM
+    S = 4096
+    want = np.zeros((S, 64, 4), np.uint64); wnum = np.zeros(S, np.int32)
+    orc.oracle().orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, S, 64, want.ctypes.data, wnum.ctypes.data, 16)
+    assert np.array_equal(num[:S], wnum)
+    assert all(np.array_equal(got[k, :wnum[k]], want[k, :wnum[k]]) for k in range(S))
