@@ -176,12 +176,13 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
             check = {"pairs_checked": len(idxs), "equal_to_oracle": bool(ok)}
         ach = b.algorithmic_bytes / (k_ms * 1e-3) / 1e9
         tr = os.path.join(ROOT, "profiles", "traffic.json")
-        sw_traffic = json.load(open(tr)).get("sw_c2", {}).get("hbm_bytes_per_launch") if os.path.exists(tr) else None
+        sw_tj = json.load(open(tr)).get("sw_c2", {}) if os.path.exists(tr) else {}
+        sw_traffic = sw_tj.get("hbm_bytes_per_launch")
         extras = {"kernel_ms": k_ms, "pairs_per_gpu": b.n, "cells_per_gpu": b.cells,
                   "with_cigar": {"ms_per_step": cigar_ms, "value": b.cells / (cigar_ms * 1e-3) / 1e9, "unit": "GCUPS",
                                  "note": "fill + backtrace + packed CIGARs back in host memory, wall clock per pass"},
                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": sw_traffic, "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
+                               "traffic": sw_traffic, "pmc": sw_tj.get("counters"), "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": b.algorithmic_bytes,
                                "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
                                         "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
@@ -426,6 +427,7 @@ def main():
         if os.path.exists(tr):
             tj = json.load(open(tr)).get("phmm_c1", {})
             roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            roof["pmc"] = tj.get("counters")            # rocprofv3 --pmc passes of the same workload (LDS bank conflicts among them)
             if tj.get("valu_insts_per_launch"):
                 # the roof this kernel actually runs under: wavefront VALU instructions (SQ_INSTS_VALU, PMC pass of the same
                 # workload) against the issue rate of a saturated SIMD (tools/ubench.hip: 1.04 ns per fp32 instruction at 8 waves)
