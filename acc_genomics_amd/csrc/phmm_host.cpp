@@ -373,8 +373,16 @@ void partition(accg_phmm_batch& b) {
       Quad Q;
       phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K, max_k8);
       const uint32_t per = 64 / Q.lpp;
-      for (uint32_t g = 0; g < PHMM_GROUPS; g++) Q.read[g] = (g < per && i + g < r.n_reads) ? order[i + g] : PHMM_NO_READ;
-      i += per;
+      // reads of at most 15 bases run in the reference's operation order even in fast mode (launch_f32), so they must not share
+      // a wavefront with longer ones: a group stops at that boundary
+      const bool first_tiny = b.rd[order[i]].len <= 15;
+      uint32_t take = 0;
+      for (uint32_t g = 0; g < PHMM_GROUPS; g++) {
+        const bool ok = g < per && i + g < r.n_reads && take == g && (first_tiny || b.rd[order[i + g]].len > 15);
+        Q.read[g] = ok ? order[i + g] : PHMM_NO_READ;
+        take += ok;
+      }
+      i += take;
       quads[ri].push_back(Q);
       kw[Q.K] += (uint64_t)r.n_haps;
     }
