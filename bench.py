@@ -312,9 +312,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sw-steps", type=int, default=5, help="passes over the Smith-Waterman batch (0 = skip that leg)")
-    ap.add_argument("--smem-steps", type=int, default=3, help="passes over the SMEM read batch (0 = skip that leg)")
-    ap.add_argument("--bwasw-steps", type=int, default=3, help="passes over the seed-extension batch (0 = skip that leg)")
+    ap.add_argument("--sw-steps", type=int, default=10, help="passes over the Smith-Waterman batch (0 = skip that leg)")
+    ap.add_argument("--smem-steps", type=int, default=10, help="passes over the SMEM read batch (0 = skip that leg)")
+    ap.add_argument("--bwasw-steps", type=int, default=10, help="passes over the seed-extension batch (0 = skip that leg)")
     args = ap.parse_args()
 
     import torch
