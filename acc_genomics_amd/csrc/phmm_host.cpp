@@ -346,7 +346,7 @@ void chunk_region(const accg_phmm_batch& b, const Region& r, uint64_t budget, st
   }
 }
 
-// Cuts every region into jobs = (four reads of similar length) x (a run of haplotypes).
+// Cuts every region into jobs = (the reads of one wavefront: up to eight of similar length) x (a run of haplotypes).
 // Single-wave workgroups are placed by the hardware dispatcher as slots free up, so the run length is
 // chosen to minimise the makespan of a longest-first list schedule on the resident-wave slots of the
 // chip (one prologue + 15-step fill per job against the quantisation of jobs over slots); e.g.
@@ -354,11 +354,11 @@ void chunk_region(const accg_phmm_batch& b, const Region& r, uint64_t budget, st
 void partition(accg_phmm_batch& b) {
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
-  // quads per region, by descending read length so that the four reads of a wavefront need the same K
-  struct Quad { uint32_t read[PHMM_GROUPS]; int K, lpp; };
+  // read groups per region (one group = the reads of one wavefront), by descending read length so that they need the same K
+  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp; };
   const char* e8 = getenv("ACCG_PHMM_LPP8");                 // A/B knob: largest K run with 8 lanes per read (0 = never)
   const int max_k8 = e8 ? atoi(e8) : PHMM_K8_DEFAULT;
-  std::vector<std::vector<Quad>> quads(b.regions.size());
+  std::vector<std::vector<Group>> groups(b.regions.size());
   b.sorted_reads.assign(b.rd.size(), 0);
   b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
   uint64_t kw[PHMM_MAX_K + 1] = {0};
@@ -370,7 +370,7 @@ void partition(accg_phmm_batch& b) {
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b.rd[x].len > b.rd[y].len; });
     std::copy(order.begin(), order.end(), b.sorted_reads.begin() + r.read0);
     for (uint32_t i = 0; i < r.n_reads;) {        // the longest read of a wavefront decides lanes per read and K
-      Quad Q;
+      Group Q;
       phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K, max_k8);
       const uint32_t per = 64 / Q.lpp;
       // reads of at most 15 bases run in the reference's operation order even in fast mode (launch_f32), so they must not share
@@ -383,7 +383,7 @@ void partition(accg_phmm_batch& b) {
         take += ok;
       }
       i += take;
-      quads[ri].push_back(Q);
+      groups[ri].push_back(Q);
       kw[Q.K] += (uint64_t)r.n_haps;
     }
   }
@@ -417,19 +417,19 @@ void partition(accg_phmm_batch& b) {
     uint32_t cap = 0;
     uint64_t n_jobs = 0, sig = 1469598103934665603ull;
     for (size_t ri = 0; ri < b.regions.size(); ri++) {
-      if (quads[ri].empty()) continue;
+      if (groups[ri].empty()) continue;
       runs.clear(); lens.clear();
       chunk_region(b, b.regions[ri], budget, runs, lens);
       for (uint32_t len : lens) { cap = std::max(cap, len); sig = (sig ^ len) * 1099511628211ull; }
       sig = (sig ^ 0xFFFFFFFFull) * 1099511628211ull;
-      int lastK = -1; uint64_t mult = 0;                       // quads are sorted by length: equal K come in runs
+      int lastK = -1; uint64_t mult = 0;                       // groups are sorted by length: equal K come in runs
       auto flush = [&]() { if (mult) for (uint32_t len : lens) hist[(len + 15 + prologue_steps) * (8.0 * lastK + 10.0)] += mult; };
-      for (const Quad& Q : quads[ri]) {
+      for (const Group& Q : groups[ri]) {
         if (Q.K != lastK) { flush(); lastK = Q.K; mult = 0; }
         mult++;
       }
       flush();
-      n_jobs += (uint64_t)quads[ri].size() * lens.size();
+      n_jobs += (uint64_t)groups[ri].size() * lens.size();
     }
     if (n_jobs == 0) break;
     if (sig == seen_sig) continue;                             // same chunking as the previous candidate
@@ -461,7 +461,7 @@ void partition(accg_phmm_batch& b) {
   struct Job { PhmmWork w; int K, lpp; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
-    if (quads[ri].empty()) continue;
+    if (groups[ri].empty()) continue;
     const Region& r = b.regions[ri];
     std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
     chunk_region(b, r, best_budget, runs, lens);
@@ -480,7 +480,7 @@ void partition(accg_phmm_batch& b) {
       for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
       for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += per_class[c] * (uint32_t)runs.size();
     }
-    for (const Quad& Q : quads[ri]) {
+    for (const Group& Q : groups[ri]) {
       PhmmWork w;
       for (int g = 0; g < PHMM_GROUPS; g++) w.read[g] = Q.read[g];
       w.pad_[0] = w.pad_[1] = 0;

@@ -9,14 +9,14 @@
 //     result  = sum_c (M[R][c] + X[R][c]),   Y[0][c] = INIT/H, everything else on the border 0.
 //
 // How it is mapped (a design of its own, neither the FPGA PE array nor the AVX stripes):
-//   * one wavefront = four reads of 16 lanes (reads <= 127 bp: eight reads of 8 lanes; > 255 bp: two reads on 32 lanes
+//   * one wavefront = four reads of 16 lanes (reads <= 103 bp: eight reads of 8 lanes; > 255 bp: two reads on 32 lanes
 //     each, > 511 bp: one read on all 64);
 //     read g lives in DPP row g (16 lanes); lane l of the row owns K
 //     consecutive read rows in registers (K = ceil((R+1)/16) is a template parameter, so all row
 //     state is register-resident and indexed at compile time).  Rows are right-aligned: the last
 //     read row is always (lane 15, k = K-1); the rows in front are clones of "row 0"
 //     (M = X = 0, Y = INIT/H), which makes the top border fall out of the same recurrence.
-//   * the four reads sweep the SAME haplotype stream, one column per step, skewed one column per
+//   * the reads of a wavefront sweep the SAME haplotype stream, one column per step, skewed one column per
 //     lane (lane l is at column t-l), so the inter-lane hand-off is exactly one DPP row_shr:1 of
 //     two values per step (the pre-multiplied diagonal term and the X of the row below) - no LDS,
 //     no bpermute.  Inside a lane the K rows are chained through registers.
@@ -169,7 +169,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   for (int j = 0; j < n_list; j++) {
     const uint32_t gh = a.hap_ids[hap_off + j];
     const uint32_t col = a.hp_local[gh];
-    if (RESCUE) {   // keep this haplotype only if one of the four reads underflowed in fp32 against it
+    if (RESCUE) {   // keep this haplotype only if one of the wavefront's reads underflowed in fp32 against it
       const bool under = have && g < NG && l == 0 && a.raw[out_base + col] < PHMM_MIN_ACCEPTED;
       const unsigned long long m = __ballot(under);
       if (m == 0) continue;
