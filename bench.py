@@ -251,8 +251,8 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
         extras = {"kernel_ms": k_ms, "reads_per_gpu": n_reads, "index_mb": int(bwt.nbytes >> 20), "block_lookups_per_read": lookups_per_read,
                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "smem_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
-                               "note": "64-byte index block per Occ lookup; the 64 MB index is served from L2 / Infinity Cache, the path is "
-                                       "bound by dependent-lookup latency"},
+                               "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup (the re-laid-out index serves a lookup from a 32-byte "
+                                       "half-block); the 64 MB index sits in L2 / Infinity Cache, the path is bound by dependent lookups"},
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},
                   "cpu_baseline": cpu}
     reads_done = n_reads * steps
