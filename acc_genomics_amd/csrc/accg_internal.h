@@ -13,6 +13,7 @@
 namespace accg {
 
 void set_hip_error(hipError_t e, const char* what);
+void set_error_text(const char* text);      // same slot as set_hip_error (accg_last_hip_error)
 
 #define ACCG_HIP(call)                                                         \
   do {                                                                         \

@@ -7,6 +7,7 @@
 //   struct Cigar / CigarElement, weights, strategies                   htc-sw/host/common.h:13-57
 //   FalconSWFPGA_init / _run / _release                                htc-sw/host/FalconSW_FPGA.cpp:16,28,92
 //   _smithWatermanRun (byte contract of the FPGA kernel)               htc-sw/host/smithWatermanHost.h:14, FalconSW_FPGA.cpp:53-88
+//   _init_opencl / _init_kernel_buffer / _release_smithWaterman        htc-sw/host/smithWatermanHost.h:12,13,15
 //   SWPairwiseAlignmentMultiBatch                                      htc-sw/host/FalconSW_AVX.cpp:304
 //   ocl_init / smem_ocl                                                smem/host/ocl.h:29-32
 #pragma once
@@ -109,6 +110,11 @@ void ocl_release();
 struct CigarElement { int length; int state; };
 struct Cigar { struct CigarElement cigarElements[MAX_SEQ_LENGTH]; int CigarElementNum; };
 
+// context lifecycle under the FPGA host's names (htc-sw/host/smithWatermanHost.h:12-15), called by FalconSWFPGA_init / _release
+// in the reference's order (FalconSW_FPGA.cpp:16-27,92-94)
+int _init_opencl(const char* bitstream);      // 1: device brought up now; 0: already up, or no device
+int _init_kernel_buffer();                    // loads the kernels and sizes the context's device / pinned buffers; 0
+int _release_smithWaterman();                 // gives the cached device blocks back; 0
 bool FalconSWFPGA_init(char* bitstream);
 // Returns device time in ns.  Results in place; a batch the device cannot take (length 0 or > 1535)
 // makes it return -1 with nothing written (the reference falls back to its AVX code at this point).

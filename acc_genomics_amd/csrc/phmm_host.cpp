@@ -22,6 +22,7 @@ static thread_local std::string g_hip_err;
 void set_hip_error(hipError_t e, const char* what) {
   g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
 }
+void set_error_text(const char* text) { g_hip_err = text; }
 }  // namespace accg
 
 extern "C" const char* accg_last_hip_error(void) { return g_hip_err.c_str(); }
@@ -38,6 +39,8 @@ extern "C" const char* accg_strerror(int st) {
     case ACCG_ERR_TOO_LONG: return "sequence longer than the kernel supports";
     case ACCG_ERR_HIP: return "HIP runtime error";
     case ACCG_ERR_NOMEM: return "out of memory";
+    case ACCG_ERR_RCCL: return "RCCL call failed";
+    case ACCG_ERR_NO_RCCL: return "librccl could not be loaded";
   }
   return "unknown status";
 }

@@ -33,8 +33,17 @@ struct accg_smem_batch {
 extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para,
                                       accg_smem_index** out) {
   if (!ctx) return ACCG_ERR_NOT_INITIALISED;
-  if (!out || !bwt || !bwt_para || bwt_words == 0 || bwt_words % 16) return ACCG_ERR_BAD_ARG;
+  if (!out || !bwt || !bwt_para || bwt_words == 0) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(ctx->device));
+  // The reference uploads exactly bwt_size words (smem/host/ocl.cpp:214-224) and a BWA index is generally not a whole number
+  // of 16-word blocks: a ragged tail is completed with zero words here, the caller's buffer is never read beyond its end.
+  std::vector<uint32_t> padded;
+  if (bwt_words % 16) {
+    padded.assign((bwt_words + 15) / 16 * 16, 0u);
+    memcpy(padded.data(), bwt, bwt_words * 4);
+    bwt = padded.data();
+    bwt_words = padded.size();
+  }
   std::unique_ptr<accg_smem_index> x(new accg_smem_index);
   x->ctx = ctx; x->words = bwt_words; x->primary = bwt_para[0];
   for (int c = 0; c < 5; c++) x->L2[c] = bwt_para[1 + c];

@@ -3,8 +3,13 @@
 Pairs (PairHMM, Smith-Waterman) are independent, so there is no data-path collective: every rank
 uploads, computes and reads back its own shard.  The only collective is an all-reduce of the counter
 vector uint64[4] {cells, pairs, kernel_ns, rescued} (sum) and of the wall time (max), as SURVEY.md 8e
-specifies.  Backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests."""
+specifies.  The product path is `RcclComm`: libaccg_hip.so's own accg_comm_* entry points over librccl
+(no torch in the process).  `FileComm` (plain files in a directory) and `reduce_counters` (torch.distributed,
+gloo) are test doubles for machines where the ranks cannot each have a GPU."""
+import ctypes as C
+import json
 import os
+import time
 
 import numpy as np
 
@@ -36,7 +41,7 @@ def shard_by_cost(costs, world):
 
 
 def reduce_counters(cells, pairs, kernel_ns, rescued, wall_s, dist=None, device="cpu"):
-    """All-reduce of the per-rank counters: returns (cells, pairs, kernel_ns, rescued) summed and wall max."""
+    """torch.distributed double of accg_counters_allreduce (gloo on the CPU): (cells, pairs, kernel_ns, rescued) summed, wall max."""
     import torch
     vec = torch.tensor([int(cells), int(pairs), int(kernel_ns), int(rescued)], dtype=torch.int64, device=device)
     tmax = torch.tensor([float(wall_s)], dtype=torch.float64, device=device)
@@ -59,3 +64,153 @@ def region_cost(reads_ser, haps_ser):
             p += 4 + fields * ln
         return out
     return sum(lens(reads_ser, 5)) * sum(lens(haps_ser, 1))
+
+
+# ---- communicators -----------------------------------------------------------------------------------------
+
+def comm_file_default():
+    """Where rank 0 leaves the RCCL unique id for the other ranks of this node: ACCG_COMM_FILE when the launcher set it
+    (bench.py's own spawner does), else a name all workers of one torch.distributed.run agent agree on."""
+    p = os.environ.get("ACCG_COMM_FILE")
+    if p:
+        return p
+    return "/tmp/accg_comm_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+
+
+def _wait_for(path, timeout):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rank file %s did not appear within %.0f s" % (path, timeout))
+        time.sleep(0.01)
+
+
+class RcclComm:
+    """accg_comm_* of the C ABI: RCCL all-reduce of the counter vector, unique id handed over through a file."""
+    backend = "rccl"
+
+    def __init__(self, ctx, rank, world, id_file=None, timeout=300.0):
+        from .lib import _check
+        self.ctx, self.L, self.rank, self.world, self._check = ctx, ctx.L, rank, world, _check
+        self.h = C.c_void_p()
+        idb = None
+        if world > 1:
+            path = id_file or comm_file_default()
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                _check(self.L.accg_comm_unique_id(buf))
+                with open(path + ".tmp", "wb") as f:
+                    f.write(buf.raw)
+                os.replace(path + ".tmp", path)
+            else:
+                _wait_for(path, timeout)
+                with open(path, "rb") as f:
+                    raw = f.read()
+                if len(raw) != 128:
+                    raise RuntimeError("unique id file %s has %d bytes" % (path, len(raw)))
+                buf.raw = raw
+            idb = buf
+        _check(self.L.accg_comm_init(ctx.h, rank, world, idb, C.byref(self.h)))
+        if world > 1 and rank == 0:            # comm_init is collective: every rank has read the file by now
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        self.uses_rccl = bool(self.L.accg_comm_uses_rccl(self.h))
+
+    def allreduce(self, cells, pairs, kernel_ns, rescued, wall_s):
+        from .lib import Counters
+        mine, tot, wmax = Counters(int(cells), int(pairs), int(kernel_ns), int(rescued)), Counters(), C.c_double()
+        self._check(self.L.accg_counters_allreduce(self.h, C.byref(mine), float(wall_s), C.byref(tot), C.byref(wmax)))
+        return int(tot.cells), int(tot.pairs), int(tot.kernel_ns), int(tot.rescued), float(wmax.value)
+
+    def barrier(self):
+        self._check(self.L.accg_comm_barrier(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.accg_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class FileComm:
+    """Test double with the same methods: ranks meet through files in one directory (any number of ranks per GPU, no
+    RCCL, no torch).  Used by the world-2-on-one-GPU test and by `ACCG_BENCH_SHARE_GPU=1 bench.py --gpus N` rehearsals."""
+    backend = "file"
+    uses_rccl = False
+
+    def __init__(self, ctx, rank, world, directory, timeout=600.0):
+        self.ctx, self.rank, self.world, self.dir, self.timeout, self.seq = ctx, rank, world, directory, timeout, 0
+        os.makedirs(directory, exist_ok=True)
+
+    def allreduce(self, cells, pairs, kernel_ns, rescued, wall_s):
+        if self.ctx is not None:
+            self.ctx.synchronize()
+        self.seq += 1
+        mine = os.path.join(self.dir, "ar_%d_%d.json" % (self.seq, self.rank))
+        with open(mine + ".tmp", "w") as f:
+            json.dump([int(cells), int(pairs), int(kernel_ns), int(rescued), float(wall_s)], f)
+        os.replace(mine + ".tmp", mine)
+        tot, wall = [0, 0, 0, 0], 0.0
+        for r in range(self.world):
+            p = os.path.join(self.dir, "ar_%d_%d.json" % (self.seq, r))
+            _wait_for(p, self.timeout)
+            v = json.load(open(p))
+            tot = [a + b for a, b in zip(tot, v[:4])]
+            wall = max(wall, v[4])
+        return tot[0], tot[1], tot[2], tot[3], wall
+
+    def barrier(self):
+        self.allreduce(0, 0, 0, 0, 0.0)
+
+    def close(self):
+        pass
+
+
+def open_comm(ctx, rank, world, backend=None):
+    """backend: "rccl" (default) or "file" (ACCG_COMM_BACKEND=file, directory = ACCG_COMM_FILE + ".d")."""
+    backend = backend or os.environ.get("ACCG_COMM_BACKEND", "rccl")
+    if backend == "file":
+        return FileComm(ctx, rank, world, comm_file_default() + ".d")
+    return RcclComm(ctx, rank, world)
+
+
+def gather_per_rank(comm, cells, pairs, kernel_ns, rescued, wall_s):
+    """Every rank's counters on every rank, through `world` counter all-reduces (rank r contributes to the r-th only)."""
+    out = []
+    for r in range(comm.world):
+        me = comm.rank == r
+        c, p, k, x, w = comm.allreduce(cells if me else 0, pairs if me else 0, kernel_ns if me else 0, rescued if me else 0,
+                                       wall_s if me else 0.0)
+        out.append({"rank": r, "cells": c, "pairs": p, "kernel_ns": k, "rescued": x, "wall_s": w})
+    return out
+
+
+# ---- the sharded PairHMM batch (BASELINE.json configs[3]) ----------------------------------------------------
+
+def run_sharded_phmm(ctx, comm, serialized_regions, costs, steps, warmup, mode=0):
+    """What `bench.py --gpus N` does with a multi-region batch: this rank takes its cost-balanced contiguous slice of the
+    regions (shard_by_cost), builds its own device batch, runs `steps` timed passes between barriers and reduces the counters.
+    `serialized_regions(a, b)` -> [(reads_ser, haps_ser)] for regions a..b-1, so a rank only materialises its own shard.
+    Returns (batch, shard, totals dict, per_rank list); the caller closes the batch."""
+    from .lib import PhmmBatch
+    a, b = shard_by_cost(costs, comm.world)[comm.rank]
+    batch = PhmmBatch(ctx, serialized_regions(a, b))
+    for _ in range(warmup):
+        batch.run(mode)
+    ctx.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run(mode)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    comm.barrier()
+    _, _, cnt = batch.results(want_log10=False)
+    k_ms = batch.time(mode, warmup=0, iters=max(1, min(steps, 5)))
+    cells, pairs, kns, resc, wmax = comm.allreduce(batch.cells * steps, batch.pairs * steps, int(k_ms * 1e6), int(cnt.rescued), wall)
+    per_rank = gather_per_rank(comm, batch.cells, b - a, int(k_ms * 1e6), int(cnt.rescued), wall)
+    for r in per_rank:
+        r["regions"] = r.pop("pairs")
+    totals = {"cells": cells, "pairs": pairs, "kernel_ns_sum": kns, "rescued": resc, "wall_s": wmax}
+    return batch, (a, b), totals, per_rank

@@ -2,7 +2,7 @@
 
 The reference loads an existing BWA index with libbwa (smem/main.cpp:434); here a synthetic genome is
 indexed from scratch: text = genome + reverse complement over {0,1,2,3}, suffix array by prefix doubling
-(numpy on the CPU for small genomes, torch on the GPU for the 64 MB index of configs[4]), BWT with the
+(numpy on the CPU -- the independent check of accg_smem_index_build, which builds the 64 MB index of configs[4] on the device), BWT with the
 sentinel removed, and the block layout read by smem/host/baseline.cpp:26-37: per 128 symbols 4 x uint64
 running counts followed by 8 x uint32 of 16 two-bit symbols, first symbol in the top bits."""
 import numpy as np
@@ -91,6 +91,18 @@ def build(genome_codes, device=None):
     para[1:6] = L2
     para[6] = nblk
     return out.reshape(-1), para, text
+
+
+def build_on_device(ctx, genome_codes):
+    """accg_smem_index_build: the library's own constructor (prefix doubling with rocPRIM sorts on the context's device).
+    Returns (bwt uint32[n_blocks*16], para uint64[7]) -- the same arrays build() gives."""
+    from .lib import _check
+    g = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    words = int(ctx.L.accg_smem_index_words(len(g)))
+    bwt = np.zeros(words, np.uint32)
+    para = np.zeros(7, np.uint64)
+    _check(ctx.L.accg_smem_index_build(ctx.h, g.ctypes.data, len(g), bwt.ctypes.data, words, para.ctypes.data))
+    return bwt, para
 
 
 def encode_reads(reads_codes, stride=256):

@@ -59,6 +59,14 @@ def load():
     L.accg_phmm_batch_results.argtypes = [vp, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_batch_destroy.argtypes = [vp]
     L.accg_counters_pack.argtypes = [C.POINTER(Counters), C.POINTER(C.c_uint64)]
+    L.accg_ctx_synchronize.argtypes = [vp]
+    L.accg_ctx_trim.argtypes = [vp]
+    L.accg_comm_unique_id.argtypes = [vp]
+    L.accg_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    for n in ("accg_comm_rank", "accg_comm_world", "accg_comm_uses_rccl", "accg_comm_barrier"):
+        getattr(L, n).argtypes = [vp]
+    L.accg_counters_allreduce.argtypes = [vp, C.POINTER(Counters), C.c_double, C.POINTER(Counters), C.POINTER(C.c_double)]
+    L.accg_comm_destroy.argtypes = [vp]
     L.accg_sw_batch_create.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     for n in ("accg_sw_batch_cells", "accg_sw_batch_algorithmic_bytes"):
         getattr(L, n).restype = C.c_uint64
@@ -72,6 +80,9 @@ def load():
     L.accg_sw_batch_cigars_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp]
     L.accg_smem_index_create.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(vp)]
     L.accg_smem_index_destroy.argtypes = [vp]
+    L.accg_smem_index_words.restype = C.c_uint64
+    L.accg_smem_index_words.argtypes = [C.c_uint64]
+    L.accg_smem_index_build.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp]
     L.accg_smem_batch_create.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.accg_smem_batch_bases.restype = C.c_uint64
     L.accg_smem_batch_bases.argtypes = [vp]
@@ -97,7 +108,7 @@ def _check(st):
     if st != 0:
         L = load()
         msg = L.accg_strerror(st).decode()
-        if st == -8:
+        if st in (-8, -10, -11):
             msg += " (" + L.accg_last_hip_error().decode() + ")"
         raise AccgError(st, msg)
 
@@ -118,6 +129,10 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def synchronize(self):
+        """accg_ctx_synchronize: everything queued on the context's stream has finished."""
+        _check(self.L.accg_ctx_synchronize(self.h))
 
     @property
     def name(self):

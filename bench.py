@@ -1,16 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: PairHMM forward GCUPS (fp32, with fp64 rescue) on BASELINE.json configs[1].
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload phmm_c1|sw_c2]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step = one pass of the hot path over one device-resident batch (inputs already in HBM).  With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank owns an independent batch of the
-same shape (weak scaling); the only collective is the RCCL all-reduce of the counter vector."""
+A step = one pass of the hot path over one device-resident batch (inputs already in HBM).
+
+N > 1: one rank per GPU.  Launched either by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly as `python bench.py --gpus N`, in which case this
+process starts the N ranks itself as child processes before anything touches a GPU and relays rank 0's line.  The ranks
+hold no torch: the barrier and the one collective -- the all-reduce of the counter vector uint64[4] {cells, pairs,
+kernel_ns, rescued} (sum) and of the wall time (max) -- are libaccg_hip.so's own accg_comm_* calls over RCCL.
+
+What the line reports at every N:
+  * `value`: configs[1] on every rank (weak scaling: the per-GPU batch is fixed, so the N = 1 line is the single-GPU
+    number of the same workload);
+  * `c3`: BASELINE.json configs[3], ONE batch of 1024 regions / 2 M pairs cut over the ranks by cell count
+    (acc_genomics_amd.dist.shard_by_cost, the reference's rule FalconPairHMM.cpp:187-197) -- strong scaling, with the
+    fp64 rescue path exercised (10 % of the reads are unrelated to every haplotype);
+  * `sw`, `smem`, `bwasw`: the other legs, every rank on a batch of its own."""
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import subprocess
+import tempfile
 import threading
 import time
 
@@ -22,6 +36,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (fp32 VALU issue, no FMA double count)
+N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32
+PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8>"
+SMEM_KERNEL_NAME = "smem_kernel<uint32_t>"
+
+
+def traffic():
+    """profiles/traffic.json: per-launch HBM bytes and instruction counts from the rocprofv3 --pmc passes (tools/prof_pmc.sh)."""
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    return json.load(open(tr)) if os.path.exists(tr) else {}
+
+
+def valu_issue(insts_per_launch, k_ms, ubench_ns=None):
+    """VALU issue roof: wavefront VALU instructions of one launch (SQ_INSTS_VALU) spread over the chip's 1024 SIMDs at the
+    guide's 2 cycles per wave64 instruction and 2.4 GHz; `frac` = that ideal time / measured kernel time."""
+    ideal_ms = insts_per_launch / N_SIMD * VALU_ISSUE_CYCLES / CLOCK_HZ * 1e3
+    out = {"insts_per_launch": insts_per_launch, "cycles_per_inst": VALU_ISSUE_CYCLES, "clock_ghz": CLOCK_HZ / 1e9,
+           "ideal_ms": ideal_ms, "frac": ideal_ms / k_ms}
+    if ubench_ns:
+        u_ms = insts_per_launch / N_SIMD * ubench_ns * 1e-6
+        out["ubench"] = {"ns_per_inst_per_simd_at_8_waves": ubench_ns, "ideal_ms": u_ms, "frac": u_ms / k_ms,
+                         "note": "tools/ubench.hip: what a saturated SIMD was measured to issue on this card"}
+    return out
 
 
 def make_c1(rank):
@@ -132,26 +168,22 @@ def cpu_baseline_sw(refs, rl, alts, al, min_wall=1.0, sample=4096):
                       % (reps, sample, wall)}
 
 
-def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
+def bench_sw(ctx, comm, steps, warmup, with_cpu):
     """Smith-Waterman leg: configs[2] on this rank's GPU; returns (cells processed, seconds, extras for rank 0)."""
     import acc_genomics_amd as A
+    rank = comm.rank
     refs, rl, alts, al, strat = make_c2(rank)
     b = A.SwBatch(ctx, refs, rl, alts, al, strategies=strat)
     for _ in range(warmup):
         b.run()
-    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h))
-    stream.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    ctx.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         b.run()
-    stream.synchronize()
-    torch.cuda.synchronize()
+    ctx.synchronize()
     t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     extras = None
     if rank == 0:
         k_ms = b.time(warmup=1, iters=max(3, steps))
@@ -175,8 +207,7 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
                 ok &= list(zip(el[k, :wn, 0].tolist(), el[k, :wn, 1].tolist())) == wcig
             check = {"pairs_checked": len(idxs), "equal_to_oracle": bool(ok)}
         ach = b.algorithmic_bytes / (k_ms * 1e-3) / 1e9
-        tr = os.path.join(ROOT, "profiles", "traffic.json")
-        sw_tj = json.load(open(tr)).get("sw_c2", {}) if os.path.exists(tr) else {}
+        sw_tj = traffic().get("sw_c2", {})
         sw_traffic = sw_tj.get("hbm_bytes_per_launch")
         extras = {"kernel_ms": k_ms, "pairs_per_gpu": b.n, "cells_per_gpu": b.cells,
                   "with_cigar": {"ms_per_step": cigar_ms, "value": b.cells / (cigar_ms * 1e-3) / 1e9, "unit": "GCUPS",
@@ -185,6 +216,7 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
                                "traffic": sw_traffic, "pmc": sw_tj.get("counters"), "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": b.algorithmic_bytes,
                                "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
+                                        "issue": valu_issue(sw_tj["valu_insts_per_launch"], k_ms, ubench_ns=1.78) if sw_tj.get("valu_insts_per_launch") else None,
                                         "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
                   "oracle_check": check,
                   "cpu_baseline": cpu_baseline_sw(refs, rl, alts, al) if with_cpu else None}
@@ -193,13 +225,14 @@ def bench_sw(ctx, rank, dist, torch, steps, warmup, with_cpu):
     return cells, t1 - t0, extras
 
 
-def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
+def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
     """SMEM leg: configs[4], n_reads x 150 bp (1 % substitutions, both strands) against the 64 MB BWT of a random genome."""
     import acc_genomics_amd as A
     from acc_genomics_amd import fmindex, synth
+    rank = comm.rank
     rng = synth.rng_for(4 + 1000 * rank)
     g = rng.integers(0, 4, size=genome_bp).astype(np.uint8)
-    bwt, para, _ = fmindex.build(g, device="cuda")        # setup: suffix array by prefix doubling on the GPU (torch)
+    bwt, para = fmindex.build_on_device(ctx, g)           # setup: the library's own suffix-array / BWT constructor
     offs = rng.integers(0, genome_bp - 150, size=n_reads)
     reads = g[offs[:, None] + np.arange(150)[None, :]]
     flip = rng.random(n_reads) < 0.5
@@ -212,17 +245,14 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
     idx = A.SmemIndex(ctx, bwt, para)
     b = A.SmemBatch(idx, seq, ln, 64)
     b.run()
-    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h))
-    stream.synchronize(); torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    ctx.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         b.run()
-    stream.synchronize(); torch.cuda.synchronize()
+    ctx.synchronize()
     t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     extras = None
     if rank == 0:
         import orc
@@ -248,11 +278,15 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
                    "sample": "%d x %d reads through oracle/smem_oracle.c (restatement of smem/host/baseline.cpp; the reference file "
                              "itself needs libbwa and cannot be built), %.2f s wall" % (reps, S, dt)}
         ach = algo / (k_ms * 1e-3) / 1e9
+        sm_tj = traffic().get("smem_c4", {})
         extras = {"kernel_ms": k_ms, "reads_per_gpu": n_reads, "index_mb": int(bwt.nbytes >> 20), "block_lookups_per_read": lookups_per_read,
-                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "smem_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
-                               "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup (the re-laid-out index serves a lookup from a 32-byte "
-                                       "half-block); the 64 MB index sits in L2 / Infinity Cache, the path is bound by dependent lookups"},
+                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": sm_tj.get("hbm_bytes_per_launch"), "pmc": sm_tj.get("counters"),
+                               "kernel": SMEM_KERNEL_NAME, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
+                               "sectors_32B": {"achieved": ach / 2, "frac": ach / 2 / HBM_PEAK_GBS,
+                                               "note": "bytes the re-laid-out index really serves: one 32-byte half-block per Occ lookup"},
+                               "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
+                                       "the path is bound by dependent lookups"},
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},
                   "cpu_baseline": cpu}
     reads_done = n_reads * steps
@@ -260,25 +294,23 @@ def bench_smem(ctx, rank, dist, torch, steps, with_cpu, genome_bp=67108864, n_re
     return reads_done, t1 - t0, extras
 
 
-def bench_bwasw(ctx, rank, dist, torch, steps, with_cpu, n_seeds=1 << 18):
+def bench_bwasw(ctx, comm, steps, with_cpu, n_seeds=1 << 18):
     """Seed-extension leg (bwa-sw): n_seeds BWA-MEM-shaped extension tasks from 150-bp reads."""
     import acc_genomics_amd as A
     from acc_genomics_amd import synth
+    rank = comm.rank
     rng = synth.rng_for(5 + 1000 * rank)
     seqs, off, par = synth.make_bwasw_seeds(rng, n_seeds, read_len=150)
     b = A.BwaswBatch(ctx, seqs, off, par)
     b.run()
-    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h))
-    stream.synchronize(); torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    ctx.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         b.run()
-    stream.synchronize(); torch.cuda.synchronize()
+    ctx.synchronize()
     t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     extras = None
     if rank == 0:
         k_ms = b.time(warmup=0, iters=max(2, steps))
@@ -297,12 +329,175 @@ def bench_bwasw(ctx, rank, dist, torch, steps, with_cpu, n_seeds=1 << 18):
             cpu = {"value": S / dt / 1e6, "unit": "Mseeds/s", "cores": th, "kind": "port",
                    "sample": "%d seeds through oracle/bwasw_oracle.c (restatement of bwa-sw/sdaccel/smithwaterman.cpp, FPGA device code "
                              "that cannot be built here), %.2f s wall" % (S, dt)}
-        extras = {"kernel_ms": k_ms, "seeds_per_gpu": n_seeds, "rect_cells_per_gpu": b.cells, "cpu_baseline": cpu,
+        bw_tj = traffic().get("bwasw", {})
+        algo = float(len(seqs) + 16 * 2 * n_seeds)      # the sequences once + one 16-byte record per side
+        ach = algo / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": bw_tj.get("hbm_bytes_per_pass"), "kernel": "bwasw_kernel<K,SIDE> (18 launches per pass)", "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": algo,
+                "valu": {"issue": valu_issue(bw_tj["valu_insts_per_pass"], k_ms) if bw_tj.get("valu_insts_per_pass") else None,
+                         "note": "integer VALU issue bound (row-per-step max-plus scan held in registers); HBM only carries the sequences"}}
+        extras = {"kernel_ms": k_ms, "seeds_per_gpu": n_seeds, "rect_cells_per_gpu": b.cells, "cpu_baseline": cpu, "roofline": roof,
                   "oracle_check": ({"seeds_checked": S, "equal_to_oracle": bw_ok} if with_cpu else None),
                   "note": "VALU-issue bound integer recurrence held in registers; HBM traffic is the sequences once (%d bytes)" % len(seqs)}
     done = n_seeds * steps
     b.close()
     return done, t1 - t0, extras
+
+
+C3_REGIONS = 1024
+
+
+def c3_shape(k):
+    """Region k of BASELINE.json configs[3]: 128 reads x 16 haplotypes, read length 70-151 and haplotype length
+    max(70, read length)-500 drawn per region; its own generator, so a rank can build just its shard."""
+    rng = np.random.default_rng([0xACC6E0 + 3, k])
+    rl = int(rng.integers(70, 152))
+    hl = int(rng.integers(max(70, rl), 501))
+    return rng, rl, hl
+
+
+def c3_region(k):
+    """1 % N bases, 10 % of the reads unrelated to every haplotype (they underflow fp32 and take the fp64 rescue path)."""
+    from acc_genomics_amd import synth
+    rng, rl, hl = c3_shape(k)
+    return synth.make_region(rng, 128, 16, rl, hl, n_frac=0.01, unrelated_frac=0.10)
+
+
+def cpu_baseline_c3(regions, min_wall=1.0):
+    """The reference's AVX path + fp64 rescue + log10 (oracle/_ref, ref_phmm_region) over whole regions of the shard, one region
+    per thread at a time, for about min_wall seconds."""
+    import orc
+    if not orc.ref_available():
+        return None
+    R = orc.ref_phmm()
+    n_threads = host_cores()
+    args = []
+    for reads, haps in regions:
+        rl = np.array([len(r["b"]) for r in reads], np.int32)
+        hl = np.array([len(h) for h in haps], np.int32)
+        keep = [orc.cstrs([r[k] for r in reads]) for k in ("b", "q", "i", "d", "c")]
+        args.append((reads, haps, rl, hl, keep, orc.cstrs(list(haps)), int(rl.sum()) * int(hl.sum())))
+    done, lock, t0 = [0, 0], threading.Lock(), time.perf_counter()
+
+    def work(tid):
+        k = tid
+        while time.perf_counter() - t0 < min_wall:
+            reads, haps, rl, hl, keep, hk, cells = args[k % len(args)]
+            l10 = np.zeros(len(reads) * len(haps), np.float64)
+            R.ref_phmm_region(1, len(reads), orc.ptr(rl, orc.i32p), *keep, len(haps), orc.ptr(hl, orc.i32p), hk, None, orc.ptr(l10, orc.f64p))
+            with lock:
+                done[0] += cells; done[1] += 1
+            k += n_threads
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    return {"value": done[0] / wall / 1e9, "unit": "GCUPS", "cores": n_threads, "kind": "reference",
+            "sample": "%d configs[3] regions (128 reads x 16 haps each) through compute_fp_avxs + rescue + log10, %.2f s wall" % (done[1], wall)}
+
+
+def bench_c3(ctx, comm, steps, warmup, mode, with_cpu):
+    """configs[3]: ONE batch of 1024 regions cut over the ranks in proportion to cell counts (strong scaling)."""
+    from acc_genomics_amd import dist as D, synth
+    costs = []
+    for k in range(C3_REGIONS):
+        _, rl, hl = c3_shape(k)
+        costs.append(128 * rl * 16 * hl)
+    mine = {}
+
+    def serialized(a, b):
+        for k in range(a, b):
+            mine[k] = c3_region(k)
+        return [(synth.serialize_reads(mine[k][0]), synth.serialize_haps(mine[k][1])) for k in range(a, b)]
+
+    t_gen = time.perf_counter()
+    batch, (a, b), tot, per_rank = D.run_sharded_phmm(ctx, comm, serialized, costs, steps, warmup, mode)
+    out = None
+    if comm.rank == 0:
+        wall = tot["wall_s"]
+        out = {"metric": "pairhmm_forward_gcups_fp32", "value": tot["cells"] / wall / 1e9, "unit": "GCUPS", "n_gpus": comm.world,
+               "scaling": "strong", "steps": steps, "ms_per_step": wall / steps * 1e3, "dtype": "f32",
+               "config": {"workload": "BASELINE.json configs[3]: 1024 regions x (128 reads of 70-151 bp x 16 haplotypes of 70-500 bp, "
+                                      "lengths per region) = 2097152 pairs in all, 1 % N, 10 % unrelated reads; fp32 sweep + fp64 rescue; "
+                                      "regions cut over the ranks by cell count (shard_by_cost)",
+                          "regions": C3_REGIONS, "pairs": tot["pairs"] // steps, "cells": tot["cells"] // steps},
+               "rescued": tot["rescued"], "rescued_frac": tot["rescued"] / max(1, tot["pairs"] // steps),
+               "per_rank": [{"rank": r["rank"], "regions": r["regions"], "cells": r["cells"], "kernel_ms": r["kernel_ns"] / 1e6,
+                             "ms_per_step": r["wall_s"] / steps * 1e3, "rescued": r["rescued"]} for r in per_rank],
+               "setup_s": time.perf_counter() - t_gen - wall}
+        if with_cpu:
+            import orc
+            O = orc.oracle()
+            _, l10, _ = batch.results()
+            off, worst, checked = 0, 0.0, 0
+            for k in range(a, b):
+                reads, haps = mine[k]
+                n = len(reads) * len(haps)
+                if (k - a) % max(1, (b - a) // 8) == 0:
+                    rl_, hl_, keep = orc.region_args(reads, haps)
+                    ol10 = np.zeros(n, np.float64)
+                    O.orc_phmm_region(len(reads), orc.ptr(rl_, orc.i32p), *keep[:5], len(haps), orc.ptr(hl_, orc.i32p), keep[5], None,
+                                      orc.ptr(ol10, orc.f64p), host_cores())
+                    worst = max(worst, float((np.abs(l10[off:off + n] - ol10) / np.abs(ol10)).max()))
+                    checked += n
+                off += n
+            out["oracle_check"] = {"pairs_checked": checked, "max_rel_err_log10": worst, "tolerance": 1e-5, "within_tolerance": bool(worst < 1e-5)}
+            if comm.world == 1:
+                out["cpu_baseline"] = cpu_baseline_c3([mine[k] for k in range(a, min(b, a + 64))])
+    batch.close()
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process (which has not touched a GPU and will not) starts the N
+    ranks as children, hands them a fresh rendezvous file for the RCCL unique id, relays rank 0's JSON line and returns the
+    first non-zero exit code."""
+    d = tempfile.mkdtemp(prefix="accg_bench_")
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", ACCG_COMM_FILE=os.path.join(d, "rccl_id"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_PORT", "29512")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+                    print("bench.py: rank %d exited with status %d; stopping the other ranks" % (r, c), file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+            time.sleep(0.05)
+        out = procs[0].stdout.read().decode()
+        if rc == 0:
+            sys.stdout.write(out)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        for f in os.listdir(d):
+            try:
+                os.unlink(os.path.join(d, f))
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
+    return rc
 
 
 def main():
@@ -312,101 +507,90 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c3-steps", type=int, default=20, help="passes over the sharded configs[3] batch (0 = skip that leg)")
     ap.add_argument("--sw-steps", type=int, default=10, help="passes over the Smith-Waterman batch (0 = skip that leg)")
     ap.add_argument("--smem-steps", type=int, default=10, help="passes over the SMEM read batch (0 = skip that leg)")
     ap.add_argument("--bwasw-steps", type=int, default=10, help="passes over the seed-extension batch (0 = skip that leg)")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: reporting the %d ranks that are really running" % (args.gpus, world, world), file=sys.stderr)
     os.environ.setdefault("NCCL_DEBUG", "WARN")     # keeps RCCL's version banner off stdout: rank 0 prints ONE JSON line
-    dist = None
-    if world > 1 or os.environ.get("ACCG_BENCH_FORCE_DIST"):     # the second form rehearses the RCCL path on one GPU
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
-    dev = local_rank if world > 1 else 0
-    torch.cuda.set_device(dev)
+    share = os.environ.get("ACCG_BENCH_SHARE_GPU")  # rehearsal on a box with fewer GPUs than ranks: every rank on device 0,
+    if share:                                       # counters through the file double (RCCL refuses two ranks on one device)
+        os.environ.setdefault("ACCG_COMM_BACKEND", "file")
+    dev = 0 if (share or world == 1) else local_rank
 
     import acc_genomics_amd as A
-    from acc_genomics_amd import synth
+    from acc_genomics_amd import dist as D, synth
     mode = A.ACCG_PHMM_FAST if args.mode == "fast" else A.ACCG_PHMM_STRICT
-    reads, haps = make_c1(rank)
     ctx = A.Context(dev)
+    comm = D.open_comm(ctx, rank, world)
+    with_cpu = not args.no_cpu_baseline
+
+    reads, haps = make_c1(rank)
     batch = A.PhmmBatch(ctx, [(synth.serialize_reads(reads), synth.serialize_haps(haps))])
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(args.warmup):
         batch.run(mode)
-    stream = torch.cuda.ExternalStream(ctx.L.accg_stream(ctx.h), device=torch.device("cuda", dev))
-    stream.synchronize()
-    barrier()
+    ctx.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.run(mode)
-    stream.synchronize()
-    torch.cuda.synchronize()
+    ctx.synchronize()
     t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     elapsed = t1 - t0
     raw, _, cnt = batch.results(want_log10=False)
     # dominant kernel: the fp32 sweep alone, HIP events on the launch stream (accg_phmm_batch_time2), taken right behind the
     # timed region (the later legs leave the card in a different power state: the same kernel then measures ~10 % slower)
-    k_ms = batch.time(mode, warmup=3, iters=50, fp32_pass_only=True) if rank == 0 else None
+    k_ms = batch.time(mode, warmup=3, iters=50, fp32_pass_only=True)
 
     # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks, wall time max over ranks (RCCL)
-    from acc_genomics_amd.dist import reduce_counters
-    total_cells, total_pairs, _, total_resc, wall = reduce_counters(batch.cells * args.steps, batch.pairs * args.steps,
-                                                                    int(elapsed * 1e9), int(cnt.rescued), elapsed, dist, "cuda")
+    total_cells, total_pairs, _, total_resc, wall = comm.allreduce(batch.cells * args.steps, batch.pairs * args.steps,
+                                                                   int(k_ms * 1e6), int(cnt.rescued), elapsed)
+
+    def leg_reduce(units, seconds):
+        u, _, _, _, t = comm.allreduce(units, 0, 0, 0, seconds)
+        return u, t
+
+    c3 = bench_c3(ctx, comm, args.c3_steps, 2, mode, with_cpu) if args.c3_steps > 0 else None
 
     sw = None
     if args.sw_steps > 0:
-        sw_cells, sw_t, sw_extras = bench_sw(ctx, rank, dist, torch, args.sw_steps, 1, not args.no_cpu_baseline)
-        v = torch.tensor([sw_cells], dtype=torch.int64, device="cuda")
-        tm = torch.tensor([sw_t], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        sw_cells, sw_t, sw_extras = bench_sw(ctx, comm, args.sw_steps, 1, with_cpu)
+        v, tm = leg_reduce(sw_cells, sw_t)
         if rank == 0:
-            sw = {"metric": "htc_sw_gcups_int16", "value": int(v[0]) / float(tm[0]) / 1e9, "unit": "GCUPS", "steps": args.sw_steps,
-                  "ms_per_step": float(tm[0]) / args.sw_steps * 1e3, "dtype": "int16",
+            sw = {"metric": "htc_sw_gcups_int16", "value": v / tm / 1e9, "unit": "GCUPS", "steps": args.sw_steps,
+                  "ms_per_step": tm / args.sw_steps * 1e3, "dtype": "int16",
                   "config": {"workload": "BASELINE.json configs[2]: 2^20 pairs per GPU, 300-bp window vs 150-bp read, "
                                          "SOFTCLIP/IGNORE halves, weights 200/-150/-260/-11, score + end cell"}}
             sw.update(sw_extras)
 
     smem = None
     if args.smem_steps > 0:
-        sm_reads, sm_t, sm_extras = bench_smem(ctx, rank, dist, torch, args.smem_steps, not args.no_cpu_baseline)
-        v = torch.tensor([sm_reads], dtype=torch.int64, device="cuda")
-        tm = torch.tensor([sm_t], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        sm_reads, sm_t, sm_extras = bench_smem(ctx, comm, args.smem_steps, with_cpu)
+        v, tm = leg_reduce(sm_reads, sm_t)
         if rank == 0:
-            smem = {"metric": "smem_seeding_mreads_per_s", "value": int(v[0]) / float(tm[0]) / 1e6, "unit": "Mreads/s", "steps": args.smem_steps,
-                    "ms_per_step": float(tm[0]) / args.smem_steps * 1e3, "dtype": "u64",
+            smem = {"metric": "smem_seeding_mreads_per_s", "value": v / tm / 1e6, "unit": "Mreads/s", "steps": args.smem_steps,
+                    "ms_per_step": tm / args.smem_steps * 1e3, "dtype": "u64",
                     "config": {"workload": "BASELINE.json configs[4]: 2^20 reads x 150 bp per GPU against a 64 MB FM-index slab "
                                            "(67108864-bp random genome + reverse complement), three-pass SMEM seeding"}}
             smem.update(sm_extras)
 
     bwasw = None
     if args.bwasw_steps > 0:
-        bw_seeds, bw_t, bw_extras = bench_bwasw(ctx, rank, dist, torch, args.bwasw_steps, not args.no_cpu_baseline)
-        v = torch.tensor([bw_seeds], dtype=torch.int64, device="cuda")
-        tm = torch.tensor([bw_t], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        bw_seeds, bw_t, bw_extras = bench_bwasw(ctx, comm, args.bwasw_steps, with_cpu)
+        v, tm = leg_reduce(bw_seeds, bw_t)
         if rank == 0:
-            bwasw = {"metric": "bwa_seed_extension_mseeds_per_s", "value": int(v[0]) / float(tm[0]) / 1e6, "unit": "Mseeds/s",
-                     "steps": args.bwasw_steps, "ms_per_step": float(tm[0]) / args.bwasw_steps * 1e3, "dtype": "int32",
+            bwasw = {"metric": "bwa_seed_extension_mseeds_per_s", "value": v / tm / 1e6, "unit": "Mseeds/s",
+                     "steps": args.bwasw_steps, "ms_per_step": tm / args.bwasw_steps * 1e3, "dtype": "int32",
                      "config": {"workload": "2^18 seeds per GPU from 150-bp reads (2 % substitutions, 15 % with a 1-5 base indel), left + "
                                             "right banded extension, 1/-4/-1, gaps 6+1, w 100"}}
             bwasw.update(bw_extras)
@@ -415,29 +599,21 @@ def main():
     if rank == 0:
         algo = batch.algorithmic_bytes
         achieved = algo / (k_ms * 1e-3) / 1e9
-        # VALU view: lane-ops actually issued per cell is ~ (10 K + 9)/ (rows per lane-step); report the algorithmic
-        # 12 flop/cell figure of SURVEY.md 8d against the fp32 vector peak as the binding roof
+        # VALU view: report the algorithmic 12 flop/cell figure of SURVEY.md 8d against the fp32 vector peak as the binding roof
         flops = 12.0 * batch.cells / (k_ms * 1e-3)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "phmm_kernel<float,K=13,lanes=8>", "kernel_ms": k_ms,
+                "traffic": None, "kernel": PHMM_KERNEL_NAME, "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo,
                 "valu": {"achieved_tflops": flops / 1e12, "peak_tflops": 157.3, "frac": flops / 157.3e12,
                          "note": "12 algorithmic flop/cell (baseline_impl.cpp:84-86); the recurrence is VALU-issue bound, not HBM bound"}}
-        tr = os.path.join(ROOT, "profiles", "traffic.json")     # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
-        if os.path.exists(tr):
-            tj = json.load(open(tr)).get("phmm_c1", {})
-            roof["traffic"] = tj.get("hbm_bytes_per_launch")
-            roof["pmc"] = tj.get("counters")            # rocprofv3 --pmc passes of the same workload (LDS bank conflicts among them)
-            if tj.get("valu_insts_per_launch"):
-                # the roof this kernel actually runs under: wavefront VALU instructions (SQ_INSTS_VALU, PMC pass of the same
-                # workload) against the issue rate of a saturated SIMD (tools/ubench.hip: 1.04 ns per fp32 instruction at 8 waves)
-                ideal_ms = tj["valu_insts_per_launch"] / 1024.0 * 1.04e-6
-                roof["valu"]["issue"] = {"insts_per_launch": tj["valu_insts_per_launch"], "ns_per_inst_per_simd_at_full_occupancy": 1.04,
-                                         "ideal_ms": ideal_ms, "frac": ideal_ms / k_ms,
-                                         "note": "resident waves per SIMD are 2 at K = 13 (189 VGPRs); the same ubench issues at 1.35 ns there"}
-        cpu = None if args.no_cpu_baseline else cpu_baseline_phmm(reads, haps)
+        tj = traffic().get("phmm_c1", {})            # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
+        roof["traffic"] = tj.get("hbm_bytes_per_launch")
+        roof["pmc"] = tj.get("counters")             # rocprofv3 --pmc passes of the same workload (LDS bank conflicts among them)
+        if tj.get("valu_insts_per_launch"):
+            roof["valu"]["issue"] = valu_issue(tj["valu_insts_per_launch"], k_ms, ubench_ns=1.04)
+        cpu = cpu_baseline_phmm(reads, haps) if with_cpu else None
         check = None
-        if not args.no_cpu_baseline:                    # the measured batch against the oracle on a sample (checker only, untimed)
+        if with_cpu:                                 # the measured batch against the oracle on a sample (checker only, untimed)
             import orc
             O = orc.oracle()
             _, l10, _ = batch.results()
@@ -451,19 +627,19 @@ def main():
             check = {"pairs_checked": len(idxs), "max_rel_err_log10": worst, "tolerance": 1e-5, "within_tolerance": bool(worst < 1e-5)}
         line = {
             "metric": "pairhmm_forward_gcups_fp32", "value": total_cells / wall / 1e9, "unit": "GCUPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: PairHMM 2048 reads (101 bp) x 32 haplotypes (300 bp) = 65536 pairs per GPU, "
                                    "fp32 sweep + fp64 rescue pass, mode=%s" % args.mode,
-                       "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name},
+                       "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name,
+                       "collective": "rccl" if comm.uses_rccl else ("none (one rank)" if comm.world == 1 else comm.backend)},
             "roofline": roof, "cpu_baseline": cpu, "oracle_check": check,
             "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
-            "sw": sw, "smem": smem, "bwasw": bwasw,
+            "c3": c3, "sw": sw, "smem": smem, "bwasw": bwasw,
         }
     batch.close()
+    comm.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
     if line is not None:
         print(json.dumps(line))
 

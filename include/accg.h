@@ -28,7 +28,9 @@ enum {
   ACCG_ERR_EMPTY_SEQ = -6,       /* zero-length read or haplotype (reference divides by haplen) */
   ACCG_ERR_TOO_LONG = -7,        /* read > ACCG_PHMM_MAX_READ or hap > ACCG_PHMM_MAX_HAP; SW length > ACCG_SW_MAX_LEN */
   ACCG_ERR_HIP = -8,             /* a HIP runtime call failed; see accg_last_hip_error() */
-  ACCG_ERR_NOMEM = -9
+  ACCG_ERR_NOMEM = -9,
+  ACCG_ERR_RCCL = -10,           /* an RCCL call failed; see accg_last_hip_error() */
+  ACCG_ERR_NO_RCCL = -11         /* a communicator over more than one rank was asked for and librccl cannot be loaded */
 };
 
 #define ACCG_PHMM_MAX_READ 1023  /* rows held in registers: up to 64 lanes x 16 rows, one row reserved */
@@ -58,7 +60,12 @@ const char* accg_strerror(int status);
 const char* accg_last_hip_error(void);
 /* the stream every launch of this context goes to (a hipStream_t) */
 void* accg_stream(accg_ctx* ctx);
+/* waits until everything queued on that stream has finished (the fence around a timed region) */
+int accg_ctx_synchronize(accg_ctx* ctx);
 int accg_device_name(accg_ctx* ctx, char* buf, size_t n);
+/* gives the context's cached device blocks and pinned staging back to the driver (the FPGA host's _release_smithWaterman,
+ * htc-sw/host/smithWatermanHost.cpp:306-320); the context stays usable */
+int accg_ctx_trim(accg_ctx* ctx);
 
 /* ---- PairHMM --------------------------------------------------------------------------------
  * One "region" = all reads x all haplotypes, given in the reference's wire format
@@ -111,7 +118,7 @@ void accg_phmm_batch_destroy(accg_phmm_batch* b);
  * the shape of SWPairwiseAlignmentMultiBatch (:304) / FalconSWFPGA_run (htc-sw/host/FalconSW_FPGA.cpp:28),
  * is the special case ref_stride = 0.
  * Results per pair: score = sw[p1][p2] and the end cell (p1, p2) that calculateCigarOneBatch starts its
- * backtrace from -- bit-exact with the CPU path.  (The CIGAR itself is SURVEY.md 8f row 3: next.)
+ * backtrace from -- bit-exact with the CPU path; accg_sw_batch_run_cigar below adds the backtrace (CIGAR, alignment_offset).
  * strategies: per pair, 0 SOFTCLIP, 1 INDEL, 2 LEADING_INDEL, 3 IGNORE (common.h:15-18); NULL = all SOFTCLIP.
  * Limits: 1 <= length <= ACCG_SW_MAX_LEN (the reference's MAX_SEQ_LENGTH - 1) for both sequences.  The shorter one is
  * spread over 16 lanes (<= 255), 32 lanes (<= 511) or a whole wavefront (<= 1535). */
@@ -146,7 +153,16 @@ void accg_sw_batch_destroy(accg_sw_batch* b);
  * PARITY of this path is unpinned: the reference file needs libbwa and cannot be built here. */
 typedef struct accg_smem_index accg_smem_index;
 typedef struct accg_smem_batch accg_smem_batch;
+/* bwt_words = the caller's true uint32 count (a BWA index is generally not a whole number of 16-word blocks: the tail is
+ * padded inside; nothing beyond bwt[bwt_words - 1] is read). */
 int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para, accg_smem_index** out);
+/* Index construction for a synthetic genome (the reference loads an existing one with libbwa's bwa_idx_load,
+ * smem/main.cpp:434; SURVEY.md 8f row 1 asks for a constructor of our own): text = genome ++ reverse complement, suffix
+ * array by prefix doubling on the device, BWT and block layout as smem/host/baseline.cpp:26-37 reads it.  genome_codes:
+ * n_genome bytes over {0,1,2,3}; bwt_out: accg_smem_index_words(n_genome) uint32; bwt_para[7] = {primary, L2[0..4], blocks}. */
+uint64_t accg_smem_index_words(uint64_t n_genome);
+int accg_smem_index_build(accg_ctx* ctx, const uint8_t* genome_codes, uint64_t n_genome, uint32_t* bwt_out, uint64_t bwt_words_cap,
+                          uint64_t* bwt_para);
 void accg_smem_index_destroy(accg_smem_index* idx);
 int accg_smem_batch_create(accg_smem_index* idx, const uint8_t* seq, uint32_t seq_stride, const uint8_t* seq_len, uint32_t n_reads,
                            uint32_t max_out, accg_smem_batch** out);
@@ -183,10 +199,29 @@ int accg_bwasw_records(accg_ctx* ctx, const int32_t* input, int64_t size, const 
                        int32_t* results, int64_t results_cap, int64_t* n_tasks);
 
 /* ---- counters (multi-GPU) ---------------------------------------------------------------------
- * Packs counters into the uint64[4] {cells, pairs, kernel_ns, rescued} vector that the ranks
- * all-reduce over RCCL; the collective itself is issued by the host harness
- * (torch.distributed, backend "nccl" == RCCL) -- no data-path collective exists. */
+ * One process per GPU; a batch is cut into contiguous shards of regions (PairHMM) or pairs (SW) in proportion to cell
+ * counts -- the rule the reference applies across its compute dies (pairhmm/xlnx/host/FalconPairHMM.cpp:169-249,
+ * cell-proportional split :187-197) -- and every rank uploads, computes and reads back its own shard.  There is no
+ * data-path collective.  What the reference adds up over its dies at the end (kernel time and cells for the GCUPS it
+ * prints, FalconPairHMM.cpp:1214-1220) is here one RCCL all-reduce over xGMI of uint64[4] {cells, pairs, kernel_ns,
+ * rescued} (sum) plus the wall time (max).  librccl is opened at run time (dlopen); a world of one needs none.
+ *
+ * Bring-up: rank 0 calls accg_comm_unique_id and hands the ACCG_COMM_ID_BYTES to the other ranks out of band (a file,
+ * a socket, the launcher's environment); every rank then calls accg_comm_init on its own context (collective). */
+#define ACCG_COMM_ID_BYTES 128
+typedef struct accg_comm accg_comm;
 void accg_counters_pack(const accg_counters* c, uint64_t out[4]);
+int accg_comm_unique_id(void* id_bytes);                       /* ncclGetUniqueId */
+int accg_comm_init(accg_ctx* ctx, int rank, int world, const void* id_bytes, accg_comm** out);   /* id may be NULL for world == 1 */
+int accg_comm_rank(const accg_comm* c);
+int accg_comm_world(const accg_comm* c);
+int accg_comm_uses_rccl(const accg_comm* c);                   /* 0 for a world of one (no collective is issued) */
+/* sum of the counters and max of wall_s over all ranks, same result on every rank; collective, waits for the context's
+ * stream.  total / wall_max may be NULL. */
+int accg_counters_allreduce(accg_comm* c, const accg_counters* mine, double wall_s, accg_counters* total, double* wall_max);
+/* this rank's stream has drained and every rank has arrived */
+int accg_comm_barrier(accg_comm* c);
+void accg_comm_destroy(accg_comm* c);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,8 @@
 #include "../../acc_genomics_amd/csrc/compat/accg_compat.h"
 #include "../../acc_genomics_amd/csrc/compat/accg_task.h"
 #include <dlfcn.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include "../../oracle/oracle.h"
 
 static std::mt19937_64 rng(0xACC6E0);
@@ -104,6 +106,8 @@ static int test_sw() {
   static struct Cigar cig[MAX_BATCH_SIZE];
   static int altLen[MAX_BATCH_SIZE], offs[MAX_BATCH_SIZE];
   const int w[4] = {W_MATCH, W_MISMATCH, W_OPEN, W_EXTEND};
+  // lifecycle in the order of FalconSW_FPGA.cpp:16-27: _init_opencl once (1), again (0: already up), _init_kernel_buffer (0)
+  if (_init_opencl("unused.xclbin") != 1 || _init_opencl("unused.xclbin") != 0 || _init_kernel_buffer() != 0) { printf("sw lifecycle\n"); return 1; }
   if (!FalconSWFPGA_init((char*)"unused")) { printf("sw init failed\n"); return 1; }
   for (int B = 1; B <= 128; B *= 2)                    // batch 1,2,4..128 as sw_host.cpp:240
     for (int strategy = 0; strategy < 4; strategy++) {
@@ -140,7 +144,14 @@ static int test_sw() {
     int off = runSWOnePairBT_fp_avx2(w[0], w[1], w[2], w[3], (uint8_t*)r, (uint8_t*)a, (int)strlen(r), (int)strlen(a), 0, &c1);
     if (cmp_cigar(c1, off, r, (int)strlen(r), a, (int)strlen(a), 0, w)) { printf("runSWOnePairBT mismatch\n"); bad++; }
   }
-  FalconSWFPGA_release();
+  FalconSWFPGA_release();                              // FalconSW_FPGA.cpp:92-94 -> _release_smithWaterman
+  if (_release_smithWaterman() != 0) bad++;
+  {   // the context stays usable after a release (the next FalconSWFPGA_run re-creates what it needs)
+    char ref[] = "ACGTACGTTAGCAGCATCGATCGACTAGCTAGGATCGATTTAGC";
+    int rl = (int)strlen(ref); altLen[0] = rl - 3; memcpy(alts[0], ref + 2, altLen[0]);
+    if (FalconSWFPGA_run(ref, rl, alts, altLen, 1, 0, w[0], w[1], w[2], w[3], cig, offs, true) < 0 ||
+        cmp_cigar(cig[0], offs[0], ref, rl, alts[0], altLen[0], 0, w)) { printf("sw after release mismatch\n"); bad++; }
+  }
   printf("htc-sw: %s\n", bad ? "FAILED" : "ok");
   return bad;
 }
@@ -181,8 +192,21 @@ static int test_smem() {
   std::vector<bwtintv_t> got((size_t)B * MAX_INTV_ALLOC), want((size_t)B * MAX_INTV_ALLOC);
   std::vector<int> gn(B), wn(B);
   double kt[BANK_NUM];
-  ocl_init((char*)"unused", bwt.data(), para, (uint64_t)bwt.size(), got.data(), B);
-  smem_ocl((char*)"unused", bwt.data(), para, seq.data(), len.data(), B, got.data(), gn.data(), kt);
+  // The array as `bwa index` writes it is not a whole number of 16-word blocks: the last block holds only the symbol words
+  // it needs and one more group of four counts follows (bwt_size = ceil(n/16) + 8 * (ceil(n/128) + 1) words; here 1510, i.e.
+  // 6 mod 16).  It is placed right in front of an inaccessible page, so that a read past bwt_size words faults.
+  const size_t sym_words = (size_t)(n + 15) / 16, real_words = sym_words + 8 * ((size_t)nblk + 1);
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE), span = (real_words * 4 + page - 1) / page * page;
+  uint8_t* map = (uint8_t*)mmap(nullptr, span + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (map == MAP_FAILED || mprotect(map + span, page, PROT_NONE) != 0) { printf("smem: mmap failed\n"); return 1; }
+  uint32_t* real = (uint32_t*)(map + span - real_words * 4);
+  const size_t head = (size_t)(nblk - 1) * 16 + 8 + (sym_words - (size_t)(nblk - 1) * 8);
+  memcpy(real, bwt.data(), head * 4);
+  memcpy(real + head, run, 32);
+  if (head + 8 != real_words || real_words % 16 == 0) { printf("smem: test layout\n"); return 1; }
+  ocl_init((char*)"unused", real, para, (uint64_t)real_words, got.data(), B);
+  smem_ocl((char*)"unused", real, para, seq.data(), len.data(), B, got.data(), gn.data(), kt);
+  munmap(map, span + page);
   orc_smem_batch(bwt.data(), para, seq.data(), SEQ_LENGTH, len.data(), B, MAX_INTV_ALLOC, (uint64_t*)want.data(), wn.data(), 2);
   int total = 0;
   for (int r = 0; r < B; r++) {

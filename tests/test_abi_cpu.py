@@ -89,6 +89,10 @@ def test_entry_points_refuse_a_null_context():
         lambda: L.accg_smem_index_create(None, buf, 16, buf, C.byref(out)),
         lambda: L.accg_bwasw_batch_create(None, 0, None, None, None, C.byref(out)),
         lambda: L.accg_bwasw_records(None, buf, 0, buf, 1, None, 0, C.byref(n)),
+        lambda: L.accg_smem_index_build(None, buf, 8, buf, 16, buf),
+        lambda: L.accg_comm_init(None, 0, 1, None, C.byref(out)),
+        lambda: L.accg_ctx_synchronize(None),
+        lambda: L.accg_ctx_trim(None),
     ]
     for k, call in enumerate(calls):
         assert call() == -2, k

@@ -85,3 +85,42 @@ def test_region_cost_matches_definition():
     reads, haps = synth.make_region(rng, 7, 3, (10, 50), (20, 80))
     want = sum(len(r["b"]) for r in reads) * sum(len(h) for h in haps)
     assert D.region_cost(synth.serialize_reads(reads), synth.serialize_haps(haps)) == want
+
+
+def _file_worker(rank, world, d, q):
+    c = D.FileComm(None, rank, world, d)
+    a = c.allreduce(10 + rank, 1, 100 * (rank + 1), rank, 0.5 + rank)
+    c.barrier()
+    per = D.gather_per_rank(c, 7 + rank, 1, 2, 3, 0.1 * (rank + 1))
+    q.put((rank, a, per))
+
+
+def test_file_comm_double_two_ranks(tmp_path):
+    """FileComm (the double used where two ranks share one GPU) reduces like accg_counters_allreduce: sums and max."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_file_worker, args=(r, 2, str(tmp_path / "c"), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, a, per in res:
+        assert a == (21, 2, 300, 1, 1.5)
+        assert [r["cells"] for r in per] == [7, 8] and [round(r["wall_s"], 3) for r in per] == [0.1, 0.2]
+
+
+def test_bench_gpus_flag_starts_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself; on a box without GPUs both fail in accg_init and the
+    parent must say so with a non-zero status instead of printing a one-GPU line."""
+    import subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "rank" in r.stderr and "no gfx950 HIP device" in r.stderr

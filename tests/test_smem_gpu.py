@@ -80,6 +80,44 @@ def test_bit_exact_vs_oracle(ctx, seed, glen, repeat, layout, monkeypatch):
     assert np.array_equal(gnum, gnum2) and np.array_equal(got, got2)
 
 
+@pytest.mark.parametrize("seed,glen,repeats", [(31, 1, 0), (32, 63, 0), (33, 64, 0), (34, 1000, 0), (35, 30000, 20), (36, 200000, 50)])
+def test_index_built_on_device_equals_numpy_build(ctx, seed, glen, repeats):
+    """accg_smem_index_build (prefix doubling with rocPRIM sorts) against the numpy construction in fmindex.build: the same block
+    array, primary and L2, including genomes with long repeats (more doubling rounds) and lengths around the block sizes."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=glen).astype(np.uint8)
+    for _ in range(repeats):
+        w = int(rng.integers(40, 400))
+        a, b = rng.integers(0, glen - w, size=2)
+        g[b:b + w] = g[a:a + w]
+    if glen == 1000:
+        g[:] = 0                                   # a homopolymer: every doubling round is needed
+    want_bwt, want_para, _ = fmindex.build(g)
+    got_bwt, got_para = fmindex.build_on_device(ctx, g)
+    assert np.array_equal(got_para, want_para)
+    assert np.array_equal(got_bwt, want_bwt)
+
+
+def test_ragged_index_size(ctx):
+    """bwt_words as `bwa index` gives it (not a multiple of 16): accepted, padded inside, same intervals."""
+    rng = np.random.default_rng(37)
+    g = rng.integers(0, 4, size=6000).astype(np.uint8)
+    bwt, para, _ = fmindex.build(g)
+    n = 2 * len(g)
+    nblk = (n + 127) // 128
+    sym_words = (n + 15) // 16
+    head = (nblk - 1) * 16 + 8 + (sym_words - (nblk - 1) * 8)
+    real = np.concatenate([bwt[:head], np.zeros(8, np.uint32)])        # ... + the trailing group of counts
+    assert len(real) % 16 != 0
+    reads = _reads(rng, g, 100, (30, 200))
+    seq, ln = fmindex.encode_reads(reads)
+    want, wnum = _oracle(bwt, para, seq, ln, 64)
+    with A.SmemIndex(ctx, real, para) as idx, A.SmemBatch(idx, seq, ln, 64) as b:
+        b.run()
+        got, gnum = b.results()
+    assert np.array_equal(gnum, wnum) and all(np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]) for k in range(len(reads)))
+
+
 def test_small_output_slot_counts_but_does_not_store(ctx):
     rng = np.random.default_rng(21)
     g = rng.integers(0, 4, size=20000).astype(np.uint8)
@@ -97,21 +135,13 @@ def test_small_output_slot_counts_but_does_not_store(ctx):
         assert np.array_equal(got[k, :min(2, gnum[k])], want[k, :min(2, gnum[k])])
 
 
-def test_full_size_c4_properties(ctx, tmp_path):
+def test_full_size_c4_properties(ctx):
     """BASELINE configs[4] at full size (2^20 reads x 150 bp against the 64 MB index of a 67 108 864-bp genome): idempotence,
     structural properties of every interval, the full-length seed of the exact reads, and 4096 reads against the oracle."""
-    import subprocess, sys
     rng = np.random.default_rng(4)
     G = 67108864
     g = rng.integers(0, 4, size=G).astype(np.uint8)
-    # the suffix array of 1.3e8 symbols is built with torch on the GPU, in a child process: torch's bundled HIP runtime does not
-    # come up in a process in which libaccg_hip.so has already initialised the device
-    np.save(tmp_path / "g.npy", g)
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); from acc_genomics_amd import fmindex; "
-            "g = np.load(%r); bwt, para, _ = fmindex.build(g, device='cuda'); np.savez(%r, bwt=bwt, para=para)"
-            % (ROOT, str(tmp_path / "g.npy"), str(tmp_path / "idx.npz")))
-    subprocess.run([sys.executable, "-c", code], check=True, timeout=600)
-    z = np.load(tmp_path / "idx.npz"); bwt, para = z["bwt"], z["para"]
+    bwt, para = fmindex.build_on_device(ctx, g)       # the library's own constructor, on the context's runtime
     n = 1 << 20
     offs = rng.integers(0, G - 150, size=n)
     reads = g[offs[:, None] + np.arange(150)[None, :]]

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a PMC summary (tools/pmc_summary.py output): per-launch HBM bytes and instruction counts that
+bench.py puts into its `roofline` objects.
+
+    python tools/make_traffic.py profiles/r02_pmc_summary.json [bwasw launches per pass, default 18]
+
+HBM bytes = (FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch, from separate --pmc passes.  The gfx950 x2 correction of
+MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads) is NOT applied: none of these
+kernels streams with 16 B per lane (byte and dword gathers), so the width is uncalibrated and the figure is a lower bound."""
+import json
+import os
+import sys
+
+src = sys.argv[1]
+bw_launches = int(sys.argv[2]) if len(sys.argv) > 2 else 18
+d = json.load(open(src))
+KEEP = ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+        "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE",
+        "TCC_HIT_sum", "TCC_MISS_sum")
+
+
+def entry(k, note=None):
+    v = d.get(k)
+    if not v:
+        return None
+    e = {"hbm_bytes_per_launch": (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0,
+         "fetch_kib": v.get("FETCH_SIZE"), "write_kib": v.get("WRITE_SIZE"), "valu_insts_per_launch": v.get("SQ_INSTS_VALU"),
+         "dispatches_seen": v.get("_dispatches_seen"), "counters": {c: v[c] for c in KEEP if c in v}}
+    if v.get("SQ_INSTS_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
+        # SQ_THREAD_CYCLES_VALU counts active lanes x 4 cycles per instruction: /4 / insts = mean active lanes of 64
+        e["active_lanes_per_valu_inst"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 4.0
+    if note:
+        e["note"] = note
+    return e
+
+
+out = {"phmm_c1": entry("phmm_f32"), "phmm_rescue_f64": entry("phmm_rescue_f64"), "sw_c2": entry("sw"),
+       "sw_c2_fill_with_backtrace_record": entry("sw_fill_bt", "mean over the scratch slices of configs[2]"),
+       "sw_trace": entry("sw_trace"), "smem_c4": entry("smem", "one launch of 2^20 reads")}
+bw = entry("bwasw", "mean over the (K, side) launches of one pass over 2^18 seeds; *_per_pass = x %d launches" % bw_launches)
+if bw:
+    bw["hbm_bytes_per_pass"] = bw["hbm_bytes_per_launch"] * bw_launches
+    bw["valu_insts_per_pass"] = (bw["valu_insts_per_launch"] or 0) * bw_launches
+    out["bwasw"] = bw
+out = {k: v for k, v in out.items() if v}
+out["source"] = os.path.relpath(src, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out["note"] = ("rocprofv3 --pmc, FETCH_SIZE / WRITE_SIZE in separate passes (tools/prof_pmc.sh), mean per dispatch, KiB units; no gfx950 x2 "
+               "read correction (no 16 B/lane streaming loads in these kernels: uncalibrated width, treat as a lower bound)")
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps({k: (v.get("hbm_bytes_per_launch"), v.get("valu_insts_per_launch")) if isinstance(v, dict) else v for k, v in out.items()}, indent=1))
