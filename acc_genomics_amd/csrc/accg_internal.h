@@ -72,6 +72,14 @@ struct accg_ctx {
 };
 
 namespace accg {
+// Declared right after the owning unique_ptr in a *_create function: an early (error) return drains the context's stream before
+// that owner's destructor hands device blocks back, so no copy queued by the failed call is still writing into them.
+struct SyncOnError {
+  hipStream_t s; bool armed = true;
+  explicit SyncOnError(hipStream_t st) : s(st) {}
+  void dismiss() { armed = false; }
+  ~SyncOnError() { if (armed) (void)hipStreamSynchronize(s); }
+};
 // aux streams wait for everything queued on ctx->stream so far / ctx->stream waits for everything queued on the aux streams
 hipError_t ctx_fork(accg_ctx* c);
 hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p);   // pinned staging of at least `bytes`

@@ -30,6 +30,7 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
   if (!out || (n_seeds && (!seqs || !seq_off || !params))) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(ctx->device));
   std::unique_ptr<accg_bwasw_batch> b(new accg_bwasw_batch);
+  SyncOnError sync_on_error(ctx->stream);
   b->ctx = ctx; b->n = n_seeds;
   std::vector<BwaswSeed> seeds(n_seeds);
   b->seed_index.resize(n_seeds);
@@ -108,6 +109,7 @@ extern "C" int accg_bwasw_batch_create(accg_ctx* ctx, uint32_t n_seeds, const ui
     ACCG_HIP(hipMemcpyAsync(b->d_work, work.data(), work.size() * sizeof(BwaswWork), hipMemcpyHostToDevice, st));
   }
   ACCG_HIP(hipStreamSynchronize(st));                // the staging and the vectors go away / get reused
+  sync_on_error.dismiss();
   *out = b.release();
   return ACCG_OK;
 }

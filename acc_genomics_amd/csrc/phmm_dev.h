@@ -16,8 +16,16 @@ constexpr int PHMM_HAPS_MAX = 48;       // haplotypes per work item
 // nchar = 4 (A C G T) or 5 (+N) -- the N slab is only carried when some haplotype of the batch has an N.
 constexpr int phmm_qt(int K, int elem_bytes) { return (K * elem_bytes + 15) / 16; }
 constexpr size_t phmm_align16(size_t x) { return (x + 15) / 16 * 16; }
-constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16) {
-  return (size_t)nchar * phmm_qt(K, elem_bytes) * 1024 + phmm_align16((size_t)(haps_cap + 1) * elem_bytes) +
+// Bytes of one base's slab of the dist table.  General layout: QT 16-byte vectors per lane, quad q at q * 1024 + lane * 16.
+// fp32 fast kernels (`compact`): the K % 4 rows behind the last full quad take 4 (one row) or 8 (two rows) bytes per lane
+// instead of 16 -- at K = 13 that is 13 KB instead of 16 KB per wavefront, i.e. 11 instead of 9 resident wavefronts per CU.
+constexpr int phmm_tail_stride(int K) { return K % 4 == 1 ? 4 : K % 4 == 2 ? 8 : K % 4 == 3 ? 16 : 0; }
+constexpr int phmm_slab_bytes(int K, int elem_bytes, bool compact) {
+  return compact ? (K / 4) * 1024 + 64 * phmm_tail_stride(K) : phmm_qt(K, elem_bytes) * 1024;
+}
+constexpr bool phmm_is_compact(int elem_bytes, bool strict) { return elem_bytes == 4 && !strict; }
+constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16, bool compact = false) {
+  return (size_t)nchar * phmm_slab_bytes(K, elem_bytes, compact) + phmm_align16((size_t)(haps_cap + 1) * elem_bytes) +
          phmm_align16((size_t)(2 * haps_cap + 3) * 4) + phmm_align16((size_t)2 * lpp + stream_cap + 24);
 }
 constexpr uint32_t PHMM_NO_READ = 0xFFFFFFFFu;
@@ -61,6 +69,7 @@ struct PhmmArgs {
   PhmmTables<T> tab;
   int nchar;                  // 4 or 5 slabs in the dist table
   int stream_cap, haps_cap;   // LDS capacities of this launch (entries / haplotypes per job)
+  int lds_min;                // host side only: ask for at least this much dynamic LDS (pins the resident wavefronts per CU)
 };
 
 // ---- fp64 rescue planning (device side, no host round trip) -----------------------------------------
@@ -95,10 +104,10 @@ struct PhmmPlanArgs {
   const SeqRef* rd;
   const uint32_t* rd_out;
   const uint32_t* read_flag;      // written by the fp32 pass
-  PhmmWork* jobs;                 // PHMM_RESCUE_CLASSES arrays of `cap` jobs each
+  PhmmWork* jobs;                 // the classes' job arrays back to back: class c at [class_off[c], class_off[c + 1])
   uint32_t* counts;               // jobs written per class
   uint32_t* flagged;              // scratch, one slot per read
-  uint32_t cap;
+  uint32_t class_off[PHMM_RESCUE_CLASSES + 1];
 };
 hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s);
 

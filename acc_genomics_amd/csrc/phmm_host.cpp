@@ -55,7 +55,9 @@ extern "C" int accg_init(int device, accg_ctx** out) {
   ACCG_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ACCG_ERR_NO_DEVICE;   // code objects are gfx950 only
   ACCG_HIP(hipSetDevice(device));
-  accg_ctx* c = new accg_ctx;
+  // a failure below hands the half-built context to accg_shutdown (streams, events, tables made so far are released)
+  struct Guard { accg_ctx* c; ~Guard() { if (c) accg_shutdown(c); } } guard{new accg_ctx};
+  accg_ctx* c = guard.c;
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, c->n_cu);
@@ -80,6 +82,7 @@ extern "C" int accg_init(int device, accg_ctx** out) {
   c->tab_d = {d, d + 128, d + 256, d + 384, t.init_d};
   c->tab_f = {f, f + 128, f + 256, f + 384, t.init_f};
   *out = c;
+  guard.c = nullptr;
   return ACCG_OK;
 }
 
@@ -255,6 +258,7 @@ struct accg_phmm_batch {
   std::vector<KLaunch> launches;
   uint64_t pairs = 0, cells = 0, algo_bytes = 0;
   bool has_n = false;          // some haplotype contains an 'N': the dist table needs its fifth slab
+  int force_wpc = 0;           // ACCG_PHMM_WPC: > 0 pins every launch to that many wavefronts per CU, < 0 pins nothing
   DevBuf<uint8_t> d_arena;       // one allocation behind every buffer below
   size_t res_off = 0;            // arena offset of the results block [n_rescued u64][out f32 x (pairs+1)]
   DevBuf<uint8_t> d_rblob, d_hblob;
@@ -268,7 +272,8 @@ struct accg_phmm_batch {
   std::vector<PhmmChunkDev> chunks_dev;
   std::vector<uint32_t> sorted_reads;
   uint32_t rescue_bound[PHMM_RESCUE_CLASSES] = {0};   // host-side upper bound of rescue jobs per class
-  uint32_t rescue_cap = 0; int rescue_stream_cap = 0, rescue_haps_cap = 0;
+  uint32_t rescue_off[PHMM_RESCUE_CLASSES + 1] = {0}; // class c's job array starts at rescue_off[c] (prefix sums of the bounds)
+  int rescue_stream_cap = 0, rescue_haps_cap = 0;
   DevBuf<PhmmRegionDev> d_regions;
   DevBuf<PhmmChunkDev> d_chunks;
   DevBuf<uint32_t> d_sorted_reads, d_flagged;
@@ -320,14 +325,18 @@ int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<Se
 }
 
 
-// Resident wavefronts per CU for the fp32 kernel at K rows per lane: LDS (160 KiB) and VGPR (512 per SIMD lane) limits.
-int waves_per_cu(int K, int nchar, int stream_cap, int haps_cap) {
-  const size_t lds = (phmm_lds_bytes(K, 4, nchar, stream_cap, haps_cap) + 511) / 512 * 512;
+// Resident wavefronts per CU for the fp32 kernel at K rows per lane: LDS (160 KiB, granted in 512-byte units) and VGPR (512
+// per SIMD lane, in units of 8) limits.  Registers as the build reports them (kernel-resource-usage): 9 K + 23 for the fast
+// kernel (column in assembly), 13 K + 23 for the strict one (compiler-scheduled).
+int waves_per_cu(int K, int nchar, int stream_cap, int haps_cap, int lpp, bool strict = false) {
+  const size_t lds = (phmm_lds_bytes(K, 4, nchar, stream_cap, haps_cap, lpp, !strict) + 511) / 512 * 512;
   const int by_lds = (int)((160 * 1024) / lds);
-  const int vgpr = (13 * K + 16 + 7) / 8 * 8;              // measured: 13 K + 16 (kernel-resource-usage)
+  const int vgpr = ((strict ? 13 : 9) * K + 23 + 7) / 8 * 8;
   const int by_vgpr = std::min(8, 512 / vgpr) * 4;
   return std::max(1, std::min(std::min(by_lds, by_vgpr), 32));
 }
+// The occupancy a launch is pinned to: 8, 16 or 32 wavefronts per CU, i.e. 2, 4 or 8 per SIMD on every SIMD (see partition()).
+int pinned_wpc(int natural) { return natural >= 32 ? 32 : natural >= 16 ? 16 : natural >= 8 ? 8 : natural; }
 
 struct Chunk { uint32_t ids0, n; uint32_t stream_len; };
 
@@ -364,7 +373,7 @@ void partition(accg_phmm_batch& b) {
   std::vector<std::vector<Group>> groups(b.regions.size());
   b.sorted_reads.assign(b.rd.size(), 0);
   b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
-  uint64_t kw[PHMM_MAX_K + 1] = {0};
+  uint64_t kw[4][PHMM_MAX_K + 1] = {{0}};     // haplotype passes per (lanes per read: 8, 16, 32, 64; K)
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     const Region& r = b.regions[ri];
     if (r.n_reads == 0 || r.n_haps == 0) continue;
@@ -387,11 +396,13 @@ void partition(accg_phmm_batch& b) {
       }
       i += take;
       groups[ri].push_back(Q);
-      kw[Q.K] += (uint64_t)r.n_haps;
+      kw[Q.lpp == 8 ? 0 : Q.lpp == 16 ? 1 : Q.lpp == 32 ? 2 : 3][Q.K] += (uint64_t)r.n_haps;
     }
   }
-  int K_dom = 1;
-  for (int k = 1; k <= PHMM_MAX_K; k++) if (kw[k] > kw[K_dom]) K_dom = k;
+  int K_dom = 1, lpp_dom = 16;
+  for (int li = 0; li < 4; li++)
+    for (int k = 1; k <= PHMM_MAX_K; k++)
+      if (kw[li][k] > kw[lpp_dom == 8 ? 0 : lpp_dom == 16 ? 1 : lpp_dom == 32 ? 2 : 3][K_dom]) { K_dom = k; lpp_dom = 8 << li; }
 
   // candidate budgets: multiples of the most common haplotype length, plus a geometric ladder
   std::vector<uint64_t> cand;
@@ -405,6 +416,9 @@ void partition(accg_phmm_batch& b) {
   cand.push_back(PHMM_STREAM_MAX);
   if (const char* e = getenv("ACCG_PHMM_STREAM_BUDGET")) { cand.clear(); cand.push_back(strtoull(e, nullptr, 10)); }   // tuning knob
 
+  const char* ew = getenv("ACCG_PHMM_WPC");                 // A/B knob: resident wavefronts per CU (8, 16, 32)
+  const int force_wpc = ew ? atoi(ew) : 0;
+  b.force_wpc = force_wpc;
   const double prologue_steps = 30.0;   // table lookups + dist table + stream build, in units of one sweep step
   uint64_t best_budget = cand[0];
   double best_span = -1;
@@ -417,16 +431,17 @@ void partition(accg_phmm_batch& b) {
   uint64_t seen_sig = 0;
   for (uint64_t budget : cand) {
     hist.clear();
-    uint32_t cap = 0;
+    uint32_t cap = 0, hmax = 1;
     uint64_t n_jobs = 0, sig = 1469598103934665603ull;
     for (size_t ri = 0; ri < b.regions.size(); ri++) {
       if (groups[ri].empty()) continue;
       runs.clear(); lens.clear();
       chunk_region(b, b.regions[ri], budget, runs, lens);
       for (uint32_t len : lens) { cap = std::max(cap, len); sig = (sig ^ len) * 1099511628211ull; }
+      for (const auto& run : runs) hmax = std::max(hmax, run.second);
       sig = (sig ^ 0xFFFFFFFFull) * 1099511628211ull;
       int lastK = -1; uint64_t mult = 0;                       // groups are sorted by length: equal K come in runs
-      auto flush = [&]() { if (mult) for (uint32_t len : lens) hist[(len + 15 + prologue_steps) * (8.0 * lastK + 10.0)] += mult; };
+      auto flush = [&]() { if (mult) for (uint32_t len : lens) hist[(len + 15 + prologue_steps) * (7.0 * lastK + 10.0)] += mult; };
       for (const Group& Q : groups[ri]) {
         if (Q.K != lastK) { flush(); lastK = Q.K; mult = 0; }
         mult++;
@@ -437,28 +452,39 @@ void partition(accg_phmm_batch& b) {
     if (n_jobs == 0) break;
     if (sig == seen_sig) continue;                             // same chunking as the previous candidate
     seen_sig = sig;
-    const int slots = n_cu * waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), PHMM_HAPS_MAX);
-    loads.clear();
-    loads[0.0] = (uint64_t)slots;
-    for (const auto& hc : hist) {
-      uint64_t left = hc.second;
-      while (left) {
-        auto lo = loads.begin();
-        const uint64_t k = std::min(left, lo->second);
-        const double nl = lo->first + hc.first;
-        if (k == lo->second) loads.erase(lo); else lo->second -= k;
-        loads[nl] += k;
-        left -= k;
+    // Resident wavefronts per CU: what registers and LDS allow, or fewer on purpose.  tools/ubench2.hip: the instruction mix of the
+    // sweep issues at 1.32 / 1.34 / 1.26 / 1.07 ns per wave-instruction per SIMD with 2 / 3 / 4 / 8 resident wavefronts and at
+    // 5 ns for a wavefront that has its SIMD to itself -- a third wavefront per SIMD buys nothing, an odd one per CU unbalances the
+    // SIMDs and a lone one at the tail is slow.  So the occupancy is one of 8, 16 or 32 per CU (the launches ask for as much LDS
+    // as it takes to get exactly that), and a slot's speed is its SIMD's rate divided by the wavefronts sharing it.
+    const int wpc_max = waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom);
+    {
+      const int wpc = force_wpc > 0 ? std::min(force_wpc, wpc_max) : force_wpc < 0 ? wpc_max : pinned_wpc(wpc_max);
+      const int w = std::max(1, wpc / 4);
+      const int slots = n_cu * wpc;
+      loads.clear();
+      loads[0.0] = (uint64_t)slots;
+      for (const auto& hc : hist) {
+        uint64_t left = hc.second;
+        while (left) {
+          auto lo = loads.begin();
+          const uint64_t k = std::min(left, lo->second);
+          const double nl = lo->first + hc.first;
+          if (k == lo->second) loads.erase(lo); else lo->second -= k;
+          loads[nl] += k;
+          left -= k;
+        }
       }
+      const double rate = w >= 8 ? 1.07 : w >= 4 ? 1.26 : w == 3 ? 1.34 : w == 2 ? 1.32 : 5.0;
+      double span = loads.rbegin()->first * rate * w;
+      // the hardware dispatcher is not an ideal list scheduler, and a slot that runs out of jobs early leaves its SIMD partner
+      // alone at a quarter of the issue rate: a mild preference for several jobs per slot
+      span *= 1.0 + 0.05 * (double)slots / (double)n_jobs;
+      // long streams cost LDS (occupancy of the launches with few rows per lane) and lengthen the tail of every launch: measured
+      // on the configs[3] mix +1 % at 2048 entries and +4.5 % at 4096 against 1300 (tools/sweep_c3.sh)
+      if (cap > 1300) span *= 1.0 + 0.03 * ((double)cap - 1300.0) / 1024.0;
+      if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
     }
-    double span = loads.rbegin()->first;
-    // more resident waves per SIMD issue VALU work faster (tools/ubench.hip: 1.35 / 1.25 / 1.16 ns per instruction at 2 / 3 / 4)
-    const int wpc = slots / n_cu;
-    span *= wpc >= 16 ? 1.0 : wpc >= 12 ? 1.08 : wpc >= 8 ? 1.16 : 1.4;
-    // the hardware dispatcher is not an ideal list scheduler: with about one job per slot it measured ~6 % behind
-    // two or four per slot on configs[1] (gpurun sweep)
-    span *= 1.0 + 0.10 * (double)slots / (double)n_jobs;
-    if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
   }
 
   struct Job { PhmmWork w; int K, lpp; uint64_t cost; uint32_t stream_len; };
@@ -521,7 +547,7 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   a.hp_local = b.d_hp_local.p; a.hap_ids = b.d_hap_ids.p; a.work = b.d_work.p; a.out = out;
   a.raw = b.d_out.p; a.n_rescued = reinterpret_cast<unsigned long long*>(b.d_state.p + state_nresc(b)); a.tab = tab;
   a.read_flag = b.d_state.p;
-  a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0; a.job_count = nullptr;
+  a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0; a.job_count = nullptr; a.lds_min = 0;
   return a;
 }
 
@@ -534,11 +560,16 @@ int launch_f32(accg_phmm_batch* b, int mode) {
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : b->ctx->stream;
+    const bool strict_l = mode == ACCG_PHMM_STRICT || l.lpp * l.K <= 16;
+    // pinned occupancy: the launch asks for as much LDS as leaves exactly 8, 16 or 32 of its wavefronts on a CU
+    const int natural = waves_per_cu(l.K, a.nchar, l.stream_cap, l.haps_cap, l.lpp, strict_l);
+    const int wpc = b->force_wpc > 0 ? std::min(b->force_wpc, natural) : b->force_wpc < 0 ? natural : pinned_wpc(natural);
+    a.lds_min = (int)((160 * 1024 / std::max(wpc, 1)) / 512 * 512);
     // Reads of at most 15 bases take the reference's operation order in fast mode too: their log10 is close to 0, where the
     // reference's float `log10f(x) - log10f(2^120)` has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
     // cleared: with them contracted the worst case over 1 500 random regions stays at that granularity, 2.4e-6.
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, mode == ACCG_PHMM_STRICT || l.lpp * l.K <= 16, a, l.work0, l.n_work, st));
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, a, l.work0, l.n_work, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -548,7 +579,8 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   PhmmPlanArgs p;
   p.regions = b->d_regions.p; p.chunks = b->d_chunks.p; p.sorted_reads = b->d_sorted_reads.p; p.rd = b->d_rd.p;
   p.rd_out = b->d_rd_out.p; p.read_flag = b->d_state.p; p.jobs = b->d_rescue_jobs.p; p.counts = b->d_state.p + state_counts(*b);
-  p.flagged = b->d_flagged.p; p.cap = b->rescue_cap;
+  p.flagged = b->d_flagged.p;
+  for (int c = 0; c <= PHMM_RESCUE_CLASSES; c++) p.class_off[c] = b->rescue_off[c];
   ACCG_HIP(phmm_rescue_plan_launch(p, (uint32_t)b->regions_dev.size(), s));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   a.work = b->d_rescue_jobs.p;
@@ -559,13 +591,13 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
   int rr = 0;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
-    const uint32_t bound = std::min(b->rescue_bound[c], b->rescue_cap);
+    const uint32_t bound = b->rescue_bound[c];
     if (!bound) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
     phmm_rescue_shape(c, &lpp_c, &k_c);
-    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, a, (uint32_t)c * b->rescue_cap, bound, st));
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, a, b->rescue_off[c], bound, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -582,6 +614,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   ACCG_HIP(hipSetDevice(ctx->device));
   PoolScope pool_scope(&ctx->pool);
   std::unique_ptr<accg_phmm_batch> b(new accg_phmm_batch);
+  SyncOnError sync_on_error(ctx->stream);
   b->ctx = ctx;
   uint64_t roff = 0, hoff = 0;
   for (int i = 0; i < n_regions; i++) { roff += reads_bytes[i]; hoff += haps_bytes[i]; }
@@ -615,8 +648,10 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const auto tp1 = std::chrono::steady_clock::now();
   hipStream_t s = ctx->stream;
   int st;
-  b->rescue_cap = 0;
-  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b->rescue_cap = std::max(b->rescue_cap, b->rescue_bound[c]);
+  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
+    if ((uint64_t)b->rescue_off[c] + b->rescue_bound[c] >= (1ull << 32)) return ACCG_ERR_TOO_LONG;
+    b->rescue_off[c + 1] = b->rescue_off[c] + b->rescue_bound[c];
+  }
   // One device arena: [uploaded tables and blobs][scratch][state | results].  The uploaded part is assembled in the context's
   // pinned staging and goes over in a single copy; the last words of `state` (n_rescued) sit right in front of `out`, so the
   // results come back in a single copy too.
@@ -629,7 +664,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
                o_sorted = take(vbytes(b->sorted_reads));
   const size_t upload_bytes = off;
   const size_t o_flagged = take((b->rd.size() + 1) * sizeof(uint32_t));
-  const size_t o_jobs = take(((size_t)b->rescue_cap * PHMM_RESCUE_CLASSES + 1) * sizeof(PhmmWork));
+  const size_t o_jobs = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(PhmmWork));
   const size_t o_out64 = take((b->pairs + 1) * sizeof(double));
   const size_t sw = state_words(*b);                         // even: the u64 counter at its end is 8-byte aligned
   const size_t o_state = take((sw + (sw & 1)) * sizeof(uint32_t) + (b->pairs + 1) * sizeof(float));
@@ -643,7 +678,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_regions.place(base, o_regions, b->regions_dev.size()); b->d_chunks.place(base, o_chunks, b->chunks_dev.size());
   b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
   b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
-  b->d_rescue_jobs.place(base, o_jobs, (size_t)b->rescue_cap * PHMM_RESCUE_CLASSES + 1);
+  b->d_rescue_jobs.place(base, o_jobs, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
   b->d_out64.place(base, o_out64, b->pairs + 1);
   b->d_state.place(base, o_state, sw);
   b->d_out.place(base, o_out, b->pairs + 1);
@@ -666,6 +701,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   ACCG_HIP(hipMemsetAsync(base + o_out64, 0, (o_out - o_out64) + (b->pairs + 1) * sizeof(float), s));   // out64, state, out
   ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
   if (getenv("ACCG_TRACE")) fprintf(stderr, "accg_phmm_batch_create: partition %.0f us, arena + upload %.0f us\n", std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count());
+  sync_on_error.dismiss();
   *out = b.release();
   return ACCG_OK;
 }

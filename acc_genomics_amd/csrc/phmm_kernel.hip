@@ -32,6 +32,7 @@
 //     are software-pipelined one step ahead of their use.
 //   * no MFMA: the recurrence is a chain of fp32 mul/fma along the anti-diagonal, not a contraction.
 #include "phmm_dev.h"
+#include <utility>
 
 namespace accg {
 namespace {
@@ -133,13 +134,136 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
   s.acc = s.acc + ((LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out);
 }
 
+// ---- fp32 fast mode: the same column, written row by row in gfx950 assembly -----------------------------------
+// Why: left to the compiler the column above needs 13 K + 23 registers (interleaved rows, two copies of the dist values,
+// Mn / Yn temporaries): 192 at K = 13 = two waves per SIMD, and a wave alone issues at most one VALU instruction per
+// four cycles, so two of them cannot cover each other's LDS waits (measured 0.58 of the issue roof).  One ascending pass,
+// every state register updated in place, needs 9 K + ~25:
+//   row k:  tn   = fma(M[k], pMM[k+1], fma(X[k], pGM[k+1], Y[k]))     the diagonal term row k+1 will multiply (old state)
+//           Y[k] = fma(M[k], pMY'[k], Y[k] * pXX[k])                   old M[k]
+//           X[k] = fma(M[k-1], pMX[k], X[k-1] * pXX[k])                new state of row k-1 (row 0: x_in straight from the DPP)
+//           M[k] = d[k] * tc                                           tc = the tn of row k-1 (row 0: a_in, DPP fused into the mul)
+// The arithmetic (operands and their order in every fma) is exactly that of column<false>: results are bit-identical.
+// The dist values of the next step are re-loaded into the same registers quad by quad as soon as a quad's rows are done.
+// LDS traffic of the fp32 fast sweep, issued and awaited by hand.  Per step and wave: one byte of the haplotype stream (the
+// slab offset two steps ahead) and the QT quads of dist values of the next step, each re-loaded into its own registers as
+// soon as its rows are done.  The compiler's s_waitcnt insertion merges the loop's back edge with the bubble block and ends up
+// waiting for the youngest load at the top of every step; counted by hand every wait is for a load issued a whole step earlier.
+// Order per step: U (stream byte), L0 .. L(QT-1); LDS operations return in order, so before any of them is consumed exactly
+// QT younger ones may still be in flight: s_waitcnt lgkmcnt(QT) everywhere.  (No scalar memory load may sit in this loop: SMEM
+// shares the counter and returns out of order.  tools/check_phmm_asm.py looks for one in the built code object.)
+template <int N> __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // low half of a flat LDS address = the LDS offset
+
+template <int REM> struct TailQuad;        // the last quad of a K that is not a multiple of four is loaded with its exact width
+template <> struct TailQuad<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct TailQuad<3> { typedef float type __attribute__((ext_vector_type(3))); };
+template <> struct TailQuad<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct TailQuad<1> { typedef float type; };
+
+template <int REM, int OFF>
+__device__ __forceinline__ void lds_load_quad(typename TailQuad<REM>::type& v, unsigned addr) {
+  if constexpr (REM == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  else if constexpr (REM == 3) asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  else if constexpr (REM == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int REM> __device__ __forceinline__ float quad_elem(const typename TailQuad<REM>::type& v, int e) { if constexpr (REM == 1) return v; else return v[e]; }
+
+// dist values of one step for the K rows of a lane: full quads + one tail of K % 4 values
+template <int K>
+struct DistRegs {
+  static constexpr int FULL = K / 4, REM = K % 4, QT = (K + 3) / 4;
+  typename TailQuad<4>::type q[FULL > 0 ? FULL : 1];
+  typename TailQuad<REM ? REM : 4>::type tail;
+  __device__ __forceinline__ float get(int k) const { return k / 4 < FULL ? q[k / 4][k % 4] : quad_elem<REM ? REM : 4>(tail, k % 4); }
+  // addr = slab + lane * 16; the tail's rows sit at FULL * 1024 + lane * phmm_tail_stride(K): tail_adj = lane * (stride - 16)
+  template <int Q> __device__ __forceinline__ void load(unsigned addr, unsigned tail_adj) {
+    if constexpr (Q < FULL) lds_load_quad<4, Q * 1024>(q[Q], addr);
+    else if constexpr (REM == 3 || REM == 0) lds_load_quad<REM ? REM : 4, Q * 1024>(tail, addr);
+    else lds_load_quad<REM, Q * 1024>(tail, addr + tail_adj);
+  }
+};
+
+template <int K, int... Q>
+__device__ __forceinline__ void load_all_quads(DistRegs<K>& dq, unsigned addr, unsigned tail_adj, std::integer_sequence<int, Q...>) { (dq.template load<Q>(addr, tail_adj), ...); }
+
+#define ACCG_DPP_ROW "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define ACCG_DPP_WAVE "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+
+template <int LPP, int K, int Q>
+__device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj, float& tc, float& a_new) {
+  if constexpr (Q < DistRegs<K>::QT) {
+    lgkm_wait<DistRegs<K>::QT>();                      // this quad's values (loaded during the previous step) have landed
+#pragma unroll
+    for (int k = 4 * Q; k < 4 * Q + 4 && k < K; k++) {
+      const float dk = dq.get(k);
+      const float gn = (k + 1 < K) ? s.pGM[k + 1] : s.nGM;
+      const float mn = (k + 1 < K) ? s.pMM[k + 1] : s.nMM;
+      float tn;
+      if (k == 0) {
+        // X[0] = x_in and M[0] = d[0] * a_in: the two lane shifts ride on the instructions that consume them
+        if (LPP <= 16) {
+          asm volatile(
+              "v_fma_f32 %[tn], %[X], %[gn], %[Y]\n\t"
+              "v_mul_f32 %[Y], %[Y], %[xx]\n\t"
+              "v_fmac_f32 %[tn], %[M], %[mn]\n\t"
+              "v_fmac_f32 %[Y], %[M], %[my]\n\t"
+              "v_mov_b32_dpp %[X], %[xo] " ACCG_DPP_ROW "\n\t"
+              "v_mul_f32_dpp %[M], %[ao], %[d] " ACCG_DPP_ROW
+              : [tn] "=&v"(tn), [X] "+v"(s.X[0]), [Y] "+v"(s.Y[0]), [M] "+v"(s.M[0])
+              : [gn] "v"(gn), [xx] "v"(s.pXX[0]), [mn] "v"(mn), [my] "v"(s.pMY[0]), [xo] "v"(s.x_out), [ao] "v"(s.a_out), [d] "v"(dk));
+        } else {
+          asm volatile(
+              "v_fma_f32 %[tn], %[X], %[gn], %[Y]\n\t"
+              "v_mul_f32 %[Y], %[Y], %[xx]\n\t"
+              "v_fmac_f32 %[tn], %[M], %[mn]\n\t"
+              "v_fmac_f32 %[Y], %[M], %[my]\n\t"
+              "v_mov_b32_dpp %[X], %[xo] " ACCG_DPP_WAVE "\n\t"
+              "v_mul_f32_dpp %[M], %[ao], %[d] " ACCG_DPP_WAVE
+              : [tn] "=&v"(tn), [X] "+v"(s.X[0]), [Y] "+v"(s.Y[0]), [M] "+v"(s.M[0])
+              : [gn] "v"(gn), [xx] "v"(s.pXX[0]), [mn] "v"(mn), [my] "v"(s.pMY[0]), [xo] "v"(s.x_out), [ao] "v"(s.a_out), [d] "v"(dk));
+        }
+      } else {
+        // every result is consumed at least three instructions after it is produced (the X product of this row is the
+        // fourth instruction after the X of the row above, the M of this row the sixth before its use by the row below)
+        asm volatile(
+            "v_fma_f32 %[tn], %[X], %[gn], %[Y]\n\t"
+            "v_mul_f32 %[Y], %[Y], %[xx]\n\t"
+            "v_mul_f32 %[X], %[Xp], %[xx]\n\t"
+            "v_fmac_f32 %[tn], %[M], %[mn]\n\t"
+            "v_fmac_f32 %[Y], %[M], %[my]\n\t"
+            "v_fmac_f32 %[X], %[Mp], %[mx]\n\t"
+            "v_mul_f32 %[M], %[d], %[tc]"
+            : [tn] "=&v"(tn), [X] "+v"(s.X[k]), [Y] "+v"(s.Y[k]), [M] "+v"(s.M[k])
+            : [gn] "v"(gn), [xx] "v"(s.pXX[k]), [mn] "v"(mn), [my] "v"(s.pMY[k]), [Xp] "v"(s.X[k - 1]), [Mp] "v"(s.M[k - 1]),
+              [mx] "v"(s.pMX[k]), [d] "v"(dk), [tc] "v"(tc));
+      }
+      if (k + 1 < K) tc = tn; else a_new = tn;
+    }
+    dq.template load<Q>(addr_next, tail_adj);          // the same registers, for the next step
+    column_rows<LPP, K, Q + 1>(s, dq, addr_next, tail_adj, tc, a_new);
+  }
+}
+
+// One column for every lane; returns what the group's last lane adds to its running sum of the last read row.
+template <int LPP, int K>
+__device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj) {
+  float tc = 0.f, a_new = 0.f;
+  column_rows<LPP, K, 0>(s, dq, addr_next, tail_adj, tc, a_new);
+  s.a_out = a_new;
+  s.x_out = fma_(s.M[K - 1], s.nMX, s.X[K - 1] * s.nXX);
+  return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;
+}
+
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
 template <typename T, int K, int LPP, bool STRICT, bool RESCUE>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
-  constexpr unsigned SLAB = QT * 1024;                 // bytes between two bases' tables
+  constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT);
+  constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
   unsigned char* tab = smem;
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
   uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
@@ -237,7 +361,13 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
       for (int e = 0; e < VN; e++)   // rs == hap || rs == 'N' || hap == 'N'   (baseline_impl.cpp:80)
         v[e] = (c == CH_N || rbase[e] == CH_N || rbase[e] == c) ? dM[e] : dX[e];
-      *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
+      if constexpr (COMPACT) {
+        if (q < K / 4 || K % 4 == 3) *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
+        else if (K % 4 == 2) { typedef float V2 __attribute__((ext_vector_type(2))); *reinterpret_cast<V2*>(tab + c * SLAB + q * 1024 + lane * 8) = V2{(float)v[0], (float)v[1]}; }
+        else *reinterpret_cast<float*>(tab + c * SLAB + q * 1024 + lane * 4) = (float)v[0];
+      } else {
+        *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
+      }
     }
   }
   {
@@ -267,9 +397,72 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   bool tiny = false;          // contracted fp64 rescue: a result close enough to the denormal range for the flush pattern to matter
   int nb = 0;                 // stream position of the next bubble lane 0 will meet
   unsigned long long rm = 0;  // bit i: lane i of every group is on a bubble this step
-  T dn[K];                    // dist of step t   (loaded one step ahead)
-  load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
+  constexpr bool ASMCOL = !STRICT && sizeof(T) == 4;   // fp32 fast mode: column_f32_asm, dist values single-buffered
   unsigned o1 = hs[1];        // base index of step t+1 (loaded two steps ahead)
+  if constexpr (ASMCOL) {
+    // One loop, one call site of the column: the state registers then have a single life range set (a second copy of the
+    // column for bubble-free runs made the register allocator keep two sets and shuffle between them).  Bubble bookkeeping is
+    // scalar (rm, nb, jn live in SGPRs), so a bubble-free step pays a few SALU instructions for it.
+    DistRegs<K> dq;           // dist of step t; re-loaded for step t+1 quad by quad inside the column
+    const unsigned tab_a = lds_addr(tab_lane), hs_a = lds_addr(hs);
+    const unsigned slab_s = __builtin_amdgcn_readfirstlane((int)SLAB);
+    const unsigned tail_adj = (unsigned)lane * (unsigned)(phmm_tail_stride(K) - 16);     // wraps: lane * stride - lane * 16
+    unsigned o1n, addr_next;  // stream byte in flight; LDS address of the next step's slab for this lane
+    {
+      // step 0's values (its slab index read and awaited on the spot), then the steady-state order: U, L0 .. L(QT-1)
+      asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_mad_u32_u24 %0, %0, %2, %3" : "=&v"(addr_next) : "v"(hs_a), "s"(slab_s), "v"(tab_a));
+      asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(o1n) : "v"(hs_a));
+      load_all_quads<K>(dq, addr_next, tail_adj, std::make_integer_sequence<int, QT>{});
+    }
+    // U steps per loop iteration, in one straight line (a taken branch costs a wave some 30 cycles: with a loop back edge, a
+    // bubble test and a "next bubble" test per step the single-step form of this loop lost 15 %).  The trip count is rounded up:
+    // the steps past t_end run over the stream's padding after the terminal bubble and write nothing.
+    constexpr int U = 8;
+    const int t_stop = (t_end + U - 1) / U * U;
+    while (t < t_stop) {
+      const unsigned hs_t = hs_a + (unsigned)t;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        rm = (rm << 1) & (LPP == 64 ? ~0ull : ((1ull << (LPP & 63)) - 1));
+        if (__builtin_expect(t + u == nb, 0)) { rm |= 1ull; jn++; nb = __builtin_amdgcn_readfirstlane((int)bpos[jn]); }
+        // the stream byte issued one step ago has landed: address of the next step's slab, next byte on its way
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "n"(QT));
+        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
+        float contrib = column_f32_asm<LPP, K>(s, dq, addr_next, tail_adj);
+        // Is any lane on a bubble?  Asked of the scalar unit through an opaque instruction: left to itself the compiler folds
+        // this test into the per-lane one below and pays three vector instructions and an EXEC round trip on every step.
+        unsigned any_bubble;
+        asm volatile("s_or_b32 %0, %1, %2" : "=s"(any_bubble) : "s"((unsigned)rm), "s"((unsigned)(rm >> 32)) : "scc");
+        if (__builtin_expect(any_bubble != 0, 0)) {
+          asm volatile("; bubble step");     // keeps this block from being merged into the per-lane test below
+          // Some lane (one per group) is on a bubble = column 0 of its next haplotype.  Everybody ran the ordinary column; that
+          // lane now overwrites its state with the column-0 border (M = X = 0, Y = 0, clones of row 0: Y = INIT/H;
+          // baseline_impl.cpp:60-70) under EXEC.
+          if ((rm >> l) & 1ull) {
+            if (l == LPP - 1 && jl >= 0 && have) {                                       // haplotype jl is complete
+              a.out[out_base + hcol[jl]] = s.acc;
+              if (!RESCUE && a.read_flag && s.acc < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
+            }
+            jl++;
+            const T y0 = y0s[jl];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+              s.M[k] = T(0); s.X[k] = T(0);
+              s.Y[k] = (k < s.npad) ? y0 * (k + 1 < K ? s.pGM[k + 1] : s.nGM) : T(0);
+            }
+            s.x_out = T(0);
+            s.acc = T(0);
+            contrib = T(0);
+          }
+        }
+        s.acc = s.acc + contrib;
+      }
+      t += U;
+    }
+    return false;
+  }
+  T dn[K];                    // dist of step t (loaded one step ahead)
+  load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
   constexpr int U = 8;
   while (t < t_end) {
     if (rm == 0 && nb - t >= U) {          // no lane is on a bubble for the next U steps
@@ -353,9 +546,17 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
   dim3 grid(RESCUE && a.job_count ? (n_work < PHMM_RESCUE_GRID ? n_work : (uint32_t)PHMM_RESCUE_GRID) : n_work), block(64);
 #define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
-    const size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL);             \
+    size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT)); \
+    if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;                                                     \
     hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE>), grid, block, lds, st, a, work_base);         \
   } break;
+#ifdef ACCG_PHMM_DEV_SUBSET      // development builds: only the configs[1] kernels (seconds instead of minutes to compile)
+  if (lpp == 8 && K == 13) {
+    if constexpr (!RESCUE && sizeof(T) == 4) { switch (K) { ACCG_CASE(13, 8) default: return hipErrorInvalidValue; } return hipGetLastError(); }
+  }
+  if (lpp == 16 && (K == 2 || K == 7)) { switch (K) { ACCG_CASE(2, 16) ACCG_CASE(7, 16) default: return hipErrorInvalidValue; } return hipGetLastError(); }
+  return hipErrorInvalidValue;
+#else
   if (lpp == 8) {      // not for the rescue pass, whose jobs are planned on the device in 16/32/64-lane classes
     if constexpr (!RESCUE) {
       switch (K) {
@@ -375,8 +576,9 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
   } else {
     switch (K) { ACCG_CASE(9, 64) ACCG_CASE(10, 64) ACCG_CASE(12, 64) ACCG_CASE(14, 64) ACCG_CASE(16, 64) default: return hipErrorInvalidValue; }
   }
-#undef ACCG_CASE
   return hipGetLastError();
+#endif
+#undef ACCG_CASE
 }
 
 // One workgroup per region: list the reads with an fp32 result below MIN_ACCEPTED (host_type.h:21), in the
@@ -422,7 +624,7 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
       PhmmWork w;
       for (uint32_t g = 0; g < PHMM_GROUPS; g++) w.read[g] = (g < per && i + g < nf) ? out[i + g] : PHMM_NO_READ;
       w.hap_off = p.chunks[R.chunk0 + c].ids0; w.n_haps = p.chunks[R.chunk0 + c].n; w.pad_[0] = w.pad_[1] = 0;
-      if (base + c < p.cap) p.jobs[(size_t)cls * p.cap + base + c] = w;
+      if (base + c < p.class_off[cls + 1] - p.class_off[cls]) p.jobs[(size_t)p.class_off[cls] + base + c] = w;
     }
     __syncthreads();
     i += per;

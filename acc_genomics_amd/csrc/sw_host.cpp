@@ -57,6 +57,7 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   *out = nullptr;
   ACCG_HIP(hipSetDevice(ctx->device));
   std::unique_ptr<accg_sw_batch> b(new accg_sw_batch);
+  SyncOnError sync_on_error(ctx->stream);
   b->ctx = ctx; b->n = n;
   struct Item { uint32_t idx; int K, lpp, ns; bool p16, lia; };
   std::vector<Item> items(n);
@@ -138,6 +139,7 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
   a.ref_len = b->d_rl; a.alt_len = b->d_al; a.strategy = b->d_strat; a.work = b->d_work;
   a.score = b->d_score; a.p1 = b->d_p1; a.p2 = b->d_p2;
   a.w_match = w_match; a.w_mismatch = w_mismatch; a.w_open = w_open; a.w_extend = w_extend;
+  sync_on_error.dismiss();
   *out = b.release();
   return ACCG_OK;
 }

@@ -32,29 +32,7 @@ def _suffix_array_numpy(s):
         k *= 2
 
 
-def _suffix_array_torch(s, device):
-    import torch
-    n = len(s)
-    rank = torch.from_numpy(s.astype(np.int64)).to(device)
-    k = 1
-    while True:
-        nxt = torch.zeros(n, dtype=torch.int64, device=device)
-        nxt[: n - k] = rank[k:] + 1
-        key = rank * (n + 2) + nxt
-        ks, sa = torch.sort(key, stable=True)
-        diff = torch.ones(n, dtype=torch.int64, device=device)
-        diff[0] = 0
-        diff[1:] = (ks[1:] != ks[:-1]).to(torch.int64)
-        newr = torch.empty(n, dtype=torch.int64, device=device)
-        newr[sa] = torch.cumsum(diff, 0)
-        rank = newr
-        del nxt, key, ks, diff
-        if int(rank.max()) == n - 1:
-            return sa.cpu().numpy()
-        k *= 2
-
-
-def build(genome_codes, device=None):
+def build(genome_codes):
     """genome_codes: uint8 array over {0,1,2,3}.  Returns (bwt uint32[n_blocks*16], para uint64[7], text uint8[2G]).
 
     para = {primary, L2[0..4], number of 64-byte blocks}; intervals and Occ follow BWA's conventions
@@ -63,7 +41,7 @@ def build(genome_codes, device=None):
     text = np.concatenate([g, revcomp_codes(g)])
     n = len(text)
     s = np.concatenate([text.astype(np.int64) + 1, np.zeros(1, np.int64)])
-    sa = _suffix_array_torch(s, device) if device is not None else _suffix_array_numpy(s)
+    sa = _suffix_array_numpy(s)
     prev = sa - 1
     primary = int(np.nonzero(sa == 0)[0][0])
     b = np.where(prev >= 0, s[np.maximum(prev, 0)], 0)

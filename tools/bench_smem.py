@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """configs[4]: SMEM seeding of N reads x 150 bp against the 64 MB BWT of a 67 108 864-bp random genome (+ its reverse
-complement).  Index built on the GPU (torch prefix doubling)."""
+complement).  Index built on the GPU by the library's own constructor (accg_smem_index_build)."""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
 import acc_genomics_amd as A
 from acc_genomics_amd import fmindex, synth
 import orc
@@ -15,7 +14,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
 rng = synth.rng_for(4)
 t0 = time.time()
 g = rng.integers(0, 4, size=G).astype(np.uint8)
-bwt, para, _ = fmindex.build(g, device="cuda")
+with A.Context(0) as c0:
+    bwt, para = fmindex.build_on_device(c0, g)
 print("index: genome %d bp, %d MB BWT, built in %.1f s" % (G, bwt.nbytes >> 20, time.time() - t0))
 t0 = time.time()
 offs = rng.integers(0, G - 150, size=N)

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""Creates and drops many batches of every kind and reports the device memory in use before / after (hipMemGetInfo through
-torch): the context's block cache may hold on to memory, a leak would grow with the iteration count."""
+"""Creates and drops many batches of every kind and reports the device memory in use before / after (rocm-smi): the context's block cache may hold on to memory, a leak would grow with the iteration count."""
 import sys, os
-import numpy as np, torch
+import subprocess
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import acc_genomics_amd as A
 from acc_genomics_amd import synth, fmindex
 
 def used():
-    free, total = torch.cuda.mem_get_info(0)
-    return (total - free) / 2**20
+    out = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--csv"], capture_output=True, text=True).stdout.strip().splitlines()
+    return float(out[1].split(",")[2]) / 2**20
 
 rng = synth.rng_for(9)
 reads, haps = synth.make_region(rng, 64, 8, (30, 150), (100, 400), unrelated_frac=0.2)
@@ -22,7 +22,6 @@ bwt, para, _ = fmindex.build(g)
 sreads = [g[o:o + 100].copy() for o in rng.integers(0, 19000, size=128)]
 seq, ln = fmindex.encode_reads(sreads)
 bs, bo, bp = synth.make_bwasw_seeds(rng, 256)
-torch.cuda.init()
 print("start: %.0f MiB in use" % used())
 ctx = A.Context(0)
 for rep in range(3):
