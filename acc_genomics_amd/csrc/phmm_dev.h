@@ -115,7 +115,13 @@ hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hi
 // a.stream_cap / a.haps_cap = largest haplotype stream (entries, bubbles included) / haplotype count among the jobs of this launch.
 constexpr int PHMM_K8_DEFAULT = 13;   // 8 lanes per read while the rows fit K <= 13 (beyond that the 2-wave occupancy costs more than it saves)
 void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+// x6 (fast mode only): the six-operation form of the sweep, for wavefronts all of whose reads pass phmm_x6_eligible()
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+// The six-operation form keeps X divided by the row's pMX: Xs[r] = M[r-1] + c[r] Xs[r-1], c[r] = pXX[r] pMX[r-1] / pMX[r].
+// Xs is bounded by max(M) * F, F[r] = 1 + c[r] F[r-1]; M never exceeds INIT / H <= 2^120, so F <= 32 leaves a factor of 8 to
+// FLT_MAX.  Reads whose insertion qualities jump by more than ~7 dB from one base to the next push F up and stay in the
+// seven-operation form.
+constexpr float PHMM_X6_MAX_F = 32.f;
 // fp64 rescue pass: same jobs as the fp32 pass; a wavefront redoes only the haplotypes for which one of
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.
 // strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in

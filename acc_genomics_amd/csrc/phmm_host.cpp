@@ -212,7 +212,7 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K, lpp; uint32_t work0, n_work; int stream_cap, haps_cap; };
+struct KLaunch { int K, lpp; bool x6; uint32_t work0, n_work; int stream_cap, haps_cap; };
 
 thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
 struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
@@ -254,6 +254,7 @@ struct accg_phmm_batch {
   std::vector<Region> regions;
   std::vector<SeqRef> rd, hp;
   std::vector<uint32_t> rd_out, hp_local, hap_ids;
+  std::vector<uint8_t> rd_x6;    // per read: eligible for the six-operation form of the fast sweep (phmm_dev.h)
   std::vector<PhmmWork> work;
   std::vector<KLaunch> launches;
   uint64_t pairs = 0, cells = 0, algo_bytes = 0;
@@ -286,7 +287,20 @@ namespace {
 
 // Wire format (pairhmm/interface/PairHMMHostInterface.cpp:175-206): returns number of records, fills refs
 // with offsets relative to `base_off` (position of this blob inside the concatenated device blob).
-int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs) {
+// PHMM_X6_MAX_F bound of phmm_dev.h on one read: _i at p + 2 len, _c at p + 4 len
+bool x6_eligible(const uint8_t* p, int len) {
+  const HostTables& t = host_tables();
+  const uint8_t *qi = p + 2 * (size_t)len, *qc = p + 4 * (size_t)len;
+  double F = 1.0;
+  for (int r = 1; r < len; r++) {
+    const double c = (double)t.ph_f[qc[r] & 127] * (double)t.ph_f[qi[r - 1] & 127] / (double)t.ph_f[qi[r] & 127];
+    F = 1.0 + c * F;
+    if (!(F <= (double)PHMM_X6_MAX_F)) return false;
+  }
+  return true;
+}
+
+int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, std::vector<uint8_t>& x6) {
   if (bytes < 4) return ACCG_ERR_BAD_WIRE;
   int32_t n; memcpy(&n, p, 4);
   if (n < 0) return ACCG_ERR_BAD_WIRE;
@@ -299,6 +313,7 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
     if (len > ACCG_PHMM_MAX_READ) return ACCG_ERR_TOO_LONG;
     for (int k = 0; k < len; k++) if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
     refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
+    x6.push_back(x6_eligible(p + pos, len) ? 1 : 0);
     pos += 5 * (size_t)len;
   }
   return n;
@@ -367,7 +382,9 @@ void partition(accg_phmm_batch& b) {
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
   // read groups per region (one group = the reads of one wavefront), by descending read length so that they need the same K
-  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp; };
+  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp; bool x6; };
+  const char* e6 = getenv("ACCG_PHMM_X6");                   // A/B knob: 0 = never use the six-operation form
+  const bool allow_x6 = !(e6 && e6[0] == '0');
   const char* e8 = getenv("ACCG_PHMM_LPP8");                 // A/B knob: largest K run with 8 lanes per read (0 = never)
   const int max_k8 = e8 ? atoi(e8) : PHMM_K8_DEFAULT;
   std::vector<std::vector<Group>> groups(b.regions.size());
@@ -388,9 +405,12 @@ void partition(accg_phmm_batch& b) {
       // reads of at most 15 bases run in the reference's operation order even in fast mode (launch_f32), so they must not share
       // a wavefront with longer ones: a group stops at that boundary
       const bool first_tiny = b.rd[order[i]].len <= 15;
+      // ... and a wavefront runs the six-operation form only if all of its reads pass the range test: a group stops where that changes
+      Q.x6 = allow_x6 && b.rd_x6[order[i]] != 0;
       uint32_t take = 0;
       for (uint32_t g = 0; g < PHMM_GROUPS; g++) {
-        const bool ok = g < per && i + g < r.n_reads && take == g && (first_tiny || b.rd[order[i + g]].len > 15);
+        const bool ok = g < per && i + g < r.n_reads && take == g && (first_tiny || b.rd[order[i + g]].len > 15) &&
+                        (!allow_x6 || (b.rd_x6[order[i + g]] != 0) == Q.x6);
         Q.read[g] = ok ? order[i + g] : PHMM_NO_READ;
         take += ok;
       }
@@ -487,7 +507,7 @@ void partition(accg_phmm_batch& b) {
     }
   }
 
-  struct Job { PhmmWork w; int K, lpp; uint64_t cost; uint32_t stream_len; };
+  struct Job { PhmmWork w; int K, lpp; bool x6; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (groups[ri].empty()) continue;
@@ -515,19 +535,19 @@ void partition(accg_phmm_batch& b) {
       w.pad_[0] = w.pad_[1] = 0;
       for (size_t c = 0; c < runs.size(); c++) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
-        jobs.push_back({w, Q.K, Q.lpp, (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
+        jobs.push_back({w, Q.K, Q.lpp, Q.x6, (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
       }
     }
   }
   // one launch per K; inside a launch the longest jobs go first so the tail is short
   std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
-    return x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.cost > y.cost;
+    return x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.x6 != y.x6 ? x.x6 > y.x6 : x.cost > y.cost;
   });
   b.work.resize(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     b.work[i] = jobs[i].w;
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp)
-      b.launches.push_back({jobs[i].K, jobs[i].lpp, (uint32_t)i, 0, 0, 0});
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().x6 != jobs[i].x6)
+      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].x6, (uint32_t)i, 0, 0, 0});
     KLaunch& L = b.launches.back();
     L.n_work++;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
@@ -569,7 +589,7 @@ int launch_f32(accg_phmm_batch* b, int mode) {
     // reference's float `log10f(x) - log10f(2^120)` has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
     // cleared: with them contracted the worst case over 1 500 random regions stays at that granularity, 2.4e-6.
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, a, l.work0, l.n_work, st));
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, l.x6 && !strict_l, a, l.work0, l.n_work, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -623,7 +643,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   for (int i = 0; i < n_regions; i++) {
     Region r;
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
-    int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd);
+    int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd, b->rd_x6);
     if (nr < 0) return nr;
     int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp, b->has_n);
     if (nh < 0) return nh;

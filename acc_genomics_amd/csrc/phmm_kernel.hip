@@ -88,6 +88,7 @@ struct Rows {
   T nMM, nGM, nMX, nXX;   // row-0 coefficients of the lane to the right (lane 15: nMX = nXX = 1, so x_out = M + X)
   T a_out, x_out;         // what this lane hands to the right at the next step
   T acc;                  // running sum of M+X of the last read row (meaningful in lane 15)
+  T xl, gclone;           // six-operation form only: pMX of the lane's last row; pGM of the first read row behind this lane's clones
   int npad;               // local rows k < npad are clones of row 0 (they form a prefix of the lane's rows)
 };
 
@@ -191,7 +192,7 @@ __device__ __forceinline__ void load_all_quads(DistRegs<K>& dq, unsigned addr, u
 #define ACCG_DPP_ROW "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #define ACCG_DPP_WAVE "wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
 
-template <int LPP, int K, int Q>
+template <int LPP, int K, bool X6, int Q>
 __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj, float& tc, float& a_new) {
   if constexpr (Q < DistRegs<K>::QT) {
     lgkm_wait<DistRegs<K>::QT>();                      // this quad's values (loaded during the previous step) have landed
@@ -224,6 +225,20 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
               : [tn] "=&v"(tn), [X] "+v"(s.X[0]), [Y] "+v"(s.Y[0]), [M] "+v"(s.M[0])
               : [gn] "v"(gn), [xx] "v"(s.pXX[0]), [mn] "v"(mn), [my] "v"(s.pMY[0]), [xo] "v"(s.x_out), [ao] "v"(s.a_out), [d] "v"(dk));
         }
+      } else if (X6) {
+        // six-operation form: X is kept divided by the row's pMX (Xs = X / pMX[k]), so its update is one fma,
+        // Xs[k] = M[k-1] + (pXX[k] pMX[k-1] / pMX[k]) Xs[k-1], and the factor comes back inside the coefficient the diagonal
+        // term multiplies it with anyway (the pGM slot holds pGM[k+1] pMX[k], the pMX slot the chain coefficient)
+        asm volatile(
+            "v_fma_f32 %[tn], %[X], %[gn], %[Y]\n\t"
+            "v_mul_f32 %[Y], %[Y], %[xx]\n\t"
+            "v_fma_f32 %[X], %[Xp], %[mx], %[Mp]\n\t"
+            "v_fmac_f32 %[tn], %[M], %[mn]\n\t"
+            "v_fmac_f32 %[Y], %[M], %[my]\n\t"
+            "v_mul_f32 %[M], %[d], %[tc]"
+            : [tn] "=&v"(tn), [X] "+v"(s.X[k]), [Y] "+v"(s.Y[k]), [M] "+v"(s.M[k])
+            : [gn] "v"(gn), [xx] "v"(s.pXX[k]), [mn] "v"(mn), [my] "v"(s.pMY[k]), [Xp] "v"(s.X[k - 1]), [Mp] "v"(s.M[k - 1]),
+              [mx] "v"(s.pMX[k]), [d] "v"(dk), [tc] "v"(tc));
       } else {
         // every result is consumed at least three instructions after it is produced (the X product of this row is the
         // fourth instruction after the X of the row above, the M of this row the sixth before its use by the row below)
@@ -242,23 +257,29 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
       if (k + 1 < K) tc = tn; else a_new = tn;
     }
     dq.template load<Q>(addr_next, tail_adj);          // the same registers, for the next step
-    column_rows<LPP, K, Q + 1>(s, dq, addr_next, tail_adj, tc, a_new);
+    column_rows<LPP, K, X6, Q + 1>(s, dq, addr_next, tail_adj, tc, a_new);
   }
 }
 
 // One column for every lane; returns what the group's last lane adds to its running sum of the last read row.
-template <int LPP, int K>
+template <int LPP, int K, bool X6>
 __device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj) {
   float tc = 0.f, a_new = 0.f;
-  column_rows<LPP, K, 0>(s, dq, addr_next, tail_adj, tc, a_new);
+  column_rows<LPP, K, X6, 0>(s, dq, addr_next, tail_adj, tc, a_new);
   s.a_out = a_new;
+  if (X6) {
+    // Xs of row 0 of the lane to the right: the same single fma as inside a lane (nMX is 1, or 0 towards another read's lanes and
+    // in a group's last lane: the product with it is exact); the last read row's M + X = M + pMX * Xs likewise
+    s.x_out = fma_(s.X[K - 1], s.nXX, s.M[K - 1] * s.nMX);
+    return fma_(s.X[K - 1], s.xl, s.M[K - 1]);
+  }
   s.x_out = fma_(s.M[K - 1], s.nMX, s.X[K - 1] * s.nXX);
-  return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;
+  return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;   // 16 / 64 lanes: the last lane has nMX = nXX = 1, x_out = M + X
 }
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE>
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
@@ -386,6 +407,31 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
     for (int k = 0; k < K; k++) s.pMY[k] = s.pMY[k] * (k + 1 < K ? s.pGM[k + 1] : s.nGM);
   }
+  s.xl = T(0); s.gclone = T(0);
+  if constexpr (X6) {
+    // Six-operation form (see column_rows): from here on the pGM slots hold pGM[k] * pMX[k-1] (what the diagonal term of row k
+    // multiplies Xs[k-1] with), the pMX slots the chain coefficient pXX[k] * pMX[k-1] / pMX[k] (0 behind a clone of row 0, whose
+    // pMX is 0: X starts at 0 there), nGM / nXX the same two for row 0 of the lane to the right, nMX the factor of M in its Xs
+    // (1; 0 towards another read's lanes).  The pGM of the first read row is still needed as such: the clones in front of it
+    // carry Y = INIT/H * that pGM (the reset at every bubble).
+#pragma unroll
+    for (int k = 0; k < K; k++) if (k == s.npad) s.gclone = s.pGM[k];
+    if (s.npad >= K) s.gclone = s.nGM;
+    s.xl = s.pMX[K - 1];
+    const T nmx_true = s.nMX;
+    if (l == LPP - 1) {
+      s.nXX = T(0); s.nMX = T(0);                                 // nothing to hand over; the running sum takes M + pMX * Xs directly
+    } else {
+      s.nXX = nmx_true != T(0) ? (s.nXX * s.xl) / nmx_true : T(0);
+      s.nMX = T(1);
+    }
+    s.nGM = s.nGM * s.xl;
+#pragma unroll
+    for (int k = K - 1; k >= 1; k--) {
+      s.pGM[k] = s.pGM[k] * s.pMX[k - 1];
+      s.pMX[k] = s.pMX[k] != T(0) ? (s.pXX[k] * s.pMX[k - 1]) / s.pMX[k] : T(0);
+    }
+  }
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's LDS writes (table, stream) before its own reads
   __builtin_amdgcn_wave_barrier();
@@ -428,7 +474,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         // the stream byte issued one step ago has landed: address of the next step's slab, next byte on its way
         asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "n"(QT));
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
-        float contrib = column_f32_asm<LPP, K>(s, dq, addr_next, tail_adj);
+        float contrib = column_f32_asm<LPP, K, X6>(s, dq, addr_next, tail_adj);
         // Is any lane on a bubble?  Asked of the scalar unit through an opaque instruction: left to itself the compiler folds
         // this test into the per-lane one below and pays three vector instructions and an EXEC round trip on every step.
         unsigned any_bubble;
@@ -448,7 +494,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
             for (int k = 0; k < K; k++) {
               s.M[k] = T(0); s.X[k] = T(0);
-              s.Y[k] = (k < s.npad) ? y0 * (k + 1 < K ? s.pGM[k + 1] : s.nGM) : T(0);
+              s.Y[k] = (k < s.npad) ? y0 * (X6 ? s.gclone : (k + 1 < K ? s.pGM[k + 1] : s.nGM)) : T(0);
             }
             s.x_out = T(0);
             s.acc = T(0);
@@ -515,7 +561,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   return __any(tiny);
 }
 
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE>
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false>
 __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
   if (RESCUE && a.job_count) {
     // the number of jobs is only known on the device (phmm_rescue_plan); the grid is capped on the host and every wavefront
@@ -523,7 +569,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     // of one per potential job
     const uint32_t n = __builtin_amdgcn_readfirstlane(*a.job_count);
     for (uint32_t job = blockIdx.x; job < n; job += gridDim.x) {
-      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE>(a, work_base, job);
+      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, X6>(a, work_base, job);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next job rebuilds the LDS tables this one still read
       __builtin_amdgcn_wave_barrier();
       if (!STRICT && tiny) {
@@ -536,11 +582,11 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       }
     }
   } else {
-    phmm_job<T, K, LPP, STRICT, RESCUE>(a, work_base, blockIdx.x);
+    phmm_job<T, K, LPP, STRICT, RESCUE, X6>(a, work_base, blockIdx.x);
   }
 }
 
-template <typename T, bool STRICT, bool RESCUE>
+template <typename T, bool STRICT, bool RESCUE, bool X6 = false>
 hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
   if (n_work == 0) return hipSuccess;
   dim3 grid(RESCUE && a.job_count ? (n_work < PHMM_RESCUE_GRID ? n_work : (uint32_t)PHMM_RESCUE_GRID) : n_work), block(64);
@@ -548,7 +594,7 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
   case KK: {                                                                                                  \
     size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT)); \
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;                                                     \
-    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE>), grid, block, lds, st, a, work_base);         \
+    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE, X6>), grid, block, lds, st, a, work_base);         \
   } break;
 #ifdef ACCG_PHMM_DEV_SUBSET      // development builds: only the configs[1] kernels (seconds instead of minutes to compile)
   if (lpp == 8 && K == 13) {
@@ -639,8 +685,9 @@ hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hi
   return hipGetLastError();
 }
 
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return strict ? launch<float, true, false>(K, lpp, a, wb, n, s) : launch<float, false, false>(K, lpp, a, wb, n, s);
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  if (strict) return launch<float, true, false>(K, lpp, a, wb, n, s);
+  return x6 ? launch<float, false, false, true>(K, lpp, a, wb, n, s) : launch<float, false, false, false>(K, lpp, a, wb, n, s);
 }
 hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
   return launch<double, true, false>(K, lpp, a, wb, n, s);

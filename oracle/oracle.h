@@ -31,6 +31,10 @@ double orc_phmm_forward_f64(int rslen, int haplen, const char* rs, const char* q
 /* FMA-contracted evaluation order used by the GPU "fast" mode (documented in DESIGN.md). */
 float  orc_phmm_forward_f32_fma(int rslen, int haplen, const char* rs, const char* q, const char* qi,
                                 const char* qd, const char* qc, const char* hap);
+/* six-operation form of the GPU fast mode (reads that pass orc_phmm_x6_eligible); see phmm_oracle.c */
+float  orc_phmm_forward_f32_fma6(int rslen, int haplen, const char* rs, const char* q, const char* qi,
+                                 const char* qd, const char* qc, const char* hap);
+int    orc_phmm_x6_eligible(int rslen, const char* qi, const char* qc);
 
 /* Post-process of FalconPairHMM::computePairhmmAVX (FalconPairHMM.cpp:83-90):
  * raw < 1e-28f -> log10(fp64 forward) - log10(2^1020), else (double)(log10f(raw) - log10f(2^120)). */
@@ -77,6 +81,7 @@ void orc_smem_batch(const uint32_t* bwt, const uint64_t* para, const uint8_t* se
                     int batch, int max_out, uint64_t* out, int* mem_num, int n_threads);
 uint64_t orc_smem_last_lookups(void);   /* 64-byte index blocks requested by the last orc_smem_batch */
 void orc_smem_occ4(const uint32_t* bwt, const uint64_t* para, uint64_t k, uint64_t cnt[4]);
+int orc_smem_read_passes(const uint32_t* bwt, const uint64_t* para, const uint8_t* seq, int len, int max_out, uint64_t* out, int bounds[3]);
 
 /* ---- BWA-MEM seed extension (PARITY UNPINNED, see bwasw_oracle.c) ------------------------------------------------ */
 void orc_bwasw_batch(const uint8_t* seqs, const uint32_t* seq_off, const uint16_t* params, int n, int16_t* out, int n_threads);

@@ -184,6 +184,62 @@ float orc_phmm_forward_f32_fma(int rslen, int haplen, const char* rs, const char
   return res;
 }
 
+
+/* The six-operation form of the GPU fast mode: X kept divided by the row's pMX,
+ *   Xs[r][c] = fma(Xs[r-1][c], (pXX[r] * pMX[r-1]) / pMX[r], M[r-1][c])          (coefficient 0 for r = 1: X[0][c] = 0)
+ *   M[r][c]  = dist * fma(M[r-1][c-1], pMM[r], fma(Xs[r-1][c-1], pGM[r] * pMX[r-1], Yt[r-1][c-1]))
+ *   result   = sum_c fma(Xs[R][c], pMX[R], M[R][c])
+ * Yt as in orc_phmm_forward_f32_fma.  The kernel only takes this form for reads that pass orc_phmm_x6_eligible (the bound
+ * that keeps Xs clear of FLT_MAX, phmm_dev.h).  Not a reference function: the GPU's arithmetic model, as the one above. */
+int orc_phmm_x6_eligible(int rslen, const char* qi, const char* qc) {
+  ensure();
+  double F = 1.0;
+  for (int r = 1; r < rslen; r++) {
+    double c = (double)g_ph_f[qc[r] & 127] * (double)g_ph_f[qi[r - 1] & 127] / (double)g_ph_f[qi[r] & 127];
+    F = 1.0 + c * F;
+    if (!(F <= 32.0)) return 0;
+  }
+  return 1;
+}
+float orc_phmm_forward_f32_fma6(int rslen, int haplen, const char* rs, const char* q, const char* qi,
+                                const char* qd, const char* qc, const char* hap) {
+  ensure();
+  FTZ_BEGIN;
+  int R = rslen, H = haplen;
+  float* buf = (float*)malloc(sizeof(float) * 6 * (size_t)(H + 1));
+  float *Mp = buf, *Xp = Mp + H + 1, *Yp = Xp + H + 1, *Mc = Yp + H + 1, *Xc = Mc + H + 1, *Yc = Xc + H + 1;
+  float g1 = 1.0f - g_ph_f[qc[0] & 127];
+  for (int c = 0; c <= H; c++) { Mp[c] = 0.f; Xp[c] = 0.f; Yp[c] = (g_init_f / (float)H) * g1; }
+  float pMXprev = 0.f;
+  for (int r = 1; r <= R; r++) {
+    int qi_ = qi[r - 1] & 127, qd_ = qd[r - 1] & 127, qc_ = qc[r - 1] & 127, qq_ = q[r - 1] & 127;
+    float pMM = g_m2m_f[tri(qi_, qd_)], pGM = 1.0f - g_ph_f[qc_], pMX = g_ph_f[qi_], pXX = g_ph_f[qc_], pMY = g_ph_f[qd_];
+    float gnext = r < R ? 1.0f - g_ph_f[qc[r] & 127] : 0.0f;
+    float pMYg = pMY * gnext;
+    float cXt = pGM * pMXprev;                       /* what the diagonal term multiplies Xs of the row above with */
+    float cXc = (pXX * pMXprev) / pMX;               /* chain coefficient; 0 for the first row */
+    float dmis = g_ph_f[qq_] / 3.0f, dmat = 1.0f - g_ph_f[qq_];
+    char rb = rs[r - 1];
+    Mc[0] = 0.f; Xc[0] = 0.f; Yc[0] = 0.f;
+    for (int c = 1; c <= H; c++) {
+      char hb = hap[c - 1];
+      float dist = (rb == hb || rb == 'N' || hb == 'N') ? dmat : dmis;
+      float a = fmaf(Mp[c - 1], pMM, fmaf(Xp[c - 1], cXt, Yp[c - 1]));
+      Mc[c] = dist * a;
+      Xc[c] = fmaf(Xp[c], cXc, Mp[c]);
+      Yc[c] = fmaf(Mc[c - 1], pMYg, Yc[c - 1] * pXX);
+    }
+    float* t;
+    t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Yp; Yp = Yc; Yc = t;
+    pMXprev = pMX;
+  }
+  float res = 0.f;
+  for (int c = 1; c <= H; c++) res += fmaf(Xp[c], pMXprev, Mp[c]);
+  free(buf);
+  FTZ_END;
+  return res;
+}
+
 double orc_phmm_finish(float raw, int rslen, int haplen, const char* rs, const char* q, const char* qi,
                        const char* qd, const char* qc, const char* hap, int* rescued) {
   ensure();

@@ -143,21 +143,42 @@ static int seed_strategy1(const fmidx* f, int len, const uint8_t* q, int x, int 
   return len;
 }
 
-/* mem_collect_intv_new (baseline.cpp:387-422) */
-static void collect(const fmidx* f, int len, const uint8_t* seq, ivec* mem, ivec* curr, ivec* back) {
+/* mem_collect_intv_new (baseline.cpp:387-422); *n_pass1 (nullable) receives the number of first-pass entries */
+static void collect_counted(const fmidx* f, int len, const uint8_t* seq, ivec* mem, ivec* curr, ivec* back, int* n_pass1, int* n_pass2) {
   mem->n = 0;
   for (int x = 0; x < len;) x = seq[x] < 4 ? smem1a_new(f, len, seq, x, 1, mem, curr, back) : x + 1;
   const int old_n = mem->n;
+  if (n_pass1) *n_pass1 = old_n;
   for (int k = 0; k < old_n; k++) {
     const int start = (int)(mem->a[k].info >> 32), end = (int)(int32_t)mem->a[k].info;
     const uint64_t occ = mem->a[k].x[2];
     if (end - start < 28 || occ > 10) continue;                                     /* split_len, split_width */
     smem1a_new(f, len, seq, (start + end) >> 1, (int)occ + 1, mem, curr, back);
   }
+  if (n_pass2) *n_pass2 = mem->n;
   for (int x = 0; x < len;) {
     if (seq[x] < 4) { intv m; x = seed_strategy1(f, len, seq, x, MIN_SEED_LEN, 20, &m); if (m.x[2] > 0) push(mem, &m); }
     else x++;
   }
+}
+
+static void collect(const fmidx* f, int len, const uint8_t* seq, ivec* mem, ivec* curr, ivec* back) {
+  collect_counted(f, len, seq, mem, curr, back, NULL, NULL);
+}
+
+/* One read, with the boundaries between the three passes (for the from-the-definition tests): out gets all entries, bounds =
+ * {entries after pass 1, after pass 2, after pass 3}.  Returns the total. */
+int orc_smem_read_passes(const uint32_t* bwt, const uint64_t* para, const uint8_t* seq, int len, int max_out, uint64_t* out, int bounds[3]) {
+  fmidx f; f.bwt = bwt; f.primary = para[0];
+  for (int c = 0; c < 5; c++) f.L2[c] = para[1 + c];
+  ivec mem = {0, 0, 0}, curr = {0, 0, 0}, back = {0, 0, 0};
+  collect_counted(&f, len, seq, &mem, &curr, &back, &bounds[0], &bounds[1]);
+  bounds[2] = mem.n;
+  const int keep = mem.n < max_out ? mem.n : max_out;
+  memcpy(out, mem.a, sizeof(intv) * (size_t)keep);
+  const int n = mem.n;
+  free(mem.a); free(curr.a); free(back.a);
+  return n;
 }
 
 /* smem_baseline (baseline.cpp:425-463): seq is batch x seq_stride codes (0-3, >= 4 ambiguous), out is batch x max_out

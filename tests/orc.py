@@ -41,6 +41,9 @@ def oracle():
         L.orc_phmm_forward_f64.argtypes = pair + [C.c_int]
         L.orc_phmm_forward_f32_fma.restype = C.c_float
         L.orc_phmm_forward_f32_fma.argtypes = pair
+        L.orc_phmm_forward_f32_fma6.restype = C.c_float
+        L.orc_phmm_forward_f32_fma6.argtypes = pair
+        L.orc_phmm_x6_eligible.argtypes = [C.c_int, C.c_char_p, C.c_char_p]
         L.orc_phmm_finish.restype = C.c_double
         L.orc_phmm_finish.argtypes = [C.c_float] + pair + [i32p]
         L.orc_phmm_region.restype = C.c_int
@@ -63,6 +66,7 @@ def oracle():
         L.orc_bwasw_extend.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_smem_last_lookups.restype = C.c_uint64
         L.orc_smem_occ4.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_smem_read_passes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _oracle = L
     return _oracle
 

@@ -121,3 +121,89 @@ def test_seed_batch_shapes_and_edges():
     assert out[1, 1] == 0 and out[1, 3] == 0                   # qEnd = rEnd = 0
     assert (out[:, 5] >= np.array([p[4] for p in pars]) - 0).all()   # extension never lowers the seed's own score
     assert (out[:, 6] == 100).all() or set(out[:, 6].tolist()) <= {100, 200}
+
+
+# ---- seed_proc from upstream BWA's mem_chain2aln (bwamem.c), each band try computed from scratch with the recurrence above ----
+
+def _upstream_side(q, t, h0, prev):
+    """The MAX_BAND_TRY loop of mem_chain2aln for one side: w = 100 << i capped by the query length (the device passes qlen as
+    max_ins / max_del), stop when the score did not move or the best cell stayed within 3/4 of the band."""
+    res, w = None, 100
+    for i in range(2):
+        w = (100 << i) & 0xFF
+        res = ksw_extend2(q, t, h0, min(w, len(q)))
+        if res[0] == prev or res[5] < (w >> 1) + (w >> 2):
+            break
+        prev = res[0]
+    return res, w
+
+
+def _upstream_seed(lq, lt, rq, rt, seed_len, seed_qbeg):
+    """Left then right extension and the clipping decision (pen_clip 5) as mem_chain2aln composes them; returns the seven fields
+    the device emits (smithwaterman.cpp:666-670)."""
+    score = seed_len
+    (mx, qle, tle, gtle, gscore, _), wl = _upstream_side(lq, lt, seed_len, score) if len(lq) else ((seed_len, 0, 0, 0, -1, 0), 100)
+    if len(lq):
+        score = mx
+        if gscore <= 0 or gscore <= score - 5:
+            qb, rb, true = seed_qbeg - qle, -tle, score
+        else:
+            qb, rb, true = 0, -gtle, gscore
+    else:
+        qb, rb, true = seed_qbeg, 0, seed_len
+    sc0 = score
+    if len(rq):
+        (mx, qle, tle, gtle, gscore, _), wr = _upstream_side(rq, rt, sc0, sc0)
+        score = mx
+        if gscore <= 0 or gscore <= score - 5:
+            qe, re, true = qle, tle, true + score - sc0
+        else:
+            qe, re, true = len(rq), gtle, true + gscore - sc0
+    else:
+        qe, re, wr = 0, 0, 100
+    return [qb, qe, rb, re, score, true, max(wl, wr)]
+
+
+def _side(rng, qlen, gap_at=None, gap=0, div=0.02):
+    """query of qlen bases and its target (qlen + room): the target is the query with `gap` extra bases inserted at gap_at (a
+    deletion from the read's point of view) -- a long gap moves the best cell off the diagonal and forces the second band try."""
+    q = rng.integers(0, 4, size=qlen).astype(np.uint8)
+    t = q.copy()
+    if gap_at is not None:
+        t = np.concatenate([t[:gap_at], rng.integers(0, 4, size=gap).astype(np.uint8), t[gap_at:]])
+    t = np.concatenate([t, rng.integers(0, 4, size=int(rng.integers(0, 30))).astype(np.uint8)])
+    mut = rng.random(qlen) < div
+    q[mut] = rng.integers(0, 4, size=int(mut.sum()))
+    return q, t
+
+
+def test_seed_proc_matches_upstream_composition_incl_second_band():
+    """Left + right extension, clipping decision and the two band tries against mem_chain2aln's flow.  Queries stay at or below
+    200 bases, where the device's reuse of the row buffers between band tries cannot show; long deletions (80-95
+    bases) put the best cell more than 75 off the diagonal, so the second try (w = 200) really runs."""
+    O = orc.oracle()
+    rng = np.random.default_rng(33)
+    seqs, offs, pars, want = [], [], [], []
+    pos = 0
+    wide = 0
+    for k in range(300):
+        big = k % 3 == 0
+        lq_n, rq_n = int(rng.integers(0, 200)), int(rng.integers(0, 200))
+        if big:
+            lq_n, rq_n = int(rng.integers(150, 200)), int(rng.integers(150, 200))
+        lq, lt = _side(rng, lq_n, gap_at=int(rng.integers(50, 70)) if big else None, gap=int(rng.integers(80, 96)) if big else 0) if lq_n else (np.zeros(0, np.uint8),) * 2
+        rq, rt = _side(rng, rq_n, gap_at=int(rng.integers(50, 70)) if big and k % 2 else None, gap=int(rng.integers(80, 96)) if big else 0) if rq_n else (np.zeros(0, np.uint8),) * 2
+        seed_len = int(rng.integers(19, 60))
+        s = np.concatenate([lq, rq, lt, rt]).astype(np.uint8)
+        seqs.append(s); offs.append(pos); pos += len(s)
+        pars.append([len(lq), len(lt), len(rq), len(rt), seed_len, len(lq), k])
+        w = _upstream_seed(lq.tolist(), lt.tolist(), rq.tolist(), rt.tolist(), seed_len, len(lq))
+        want.append(w)
+        wide += w[6] == 200
+    seq = np.concatenate(seqs)
+    off = np.array(offs, np.uint32); par = np.array(pars, np.uint16)
+    out = np.zeros((len(pars), 7), np.int16)
+    O.orc_bwasw_batch(seq.ctypes.data, off.ctypes.data, par.ctypes.data, len(pars), out.ctypes.data, 2)
+    assert wide >= 20                                            # the second band try was needed often enough to mean something
+    bad = [(k, out[k].tolist(), want[k]) for k in range(len(pars)) if out[k].tolist() != want[k]]
+    assert not bad, bad[:3]

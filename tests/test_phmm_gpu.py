@@ -63,17 +63,53 @@ def test_golden_fast_within_tolerance(ctx, path):
     assert not ok.any() or (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < REL_TOL
 
 
-def test_fast_matches_its_arithmetic_model(ctx):
-    """The fast mode is bit-exact with oracle's FMA restatement: any difference is a kernel bug, not rounding."""
+def _model(O, r, h, x6):
+    a = orc.pair_args(r, h)
+    if len(r["b"]) <= 15:                       # reads of at most 15 bases take the reference's operation order in fast mode too
+        return O.orc_phmm_forward_f32(*a, 0)
+    return O.orc_phmm_forward_f32_fma6(*a) if x6 else O.orc_phmm_forward_f32_fma(*a)
+
+
+def test_fast_matches_its_arithmetic_model(ctx, monkeypatch):
+    """The fast mode is bit-exact with the oracle's restatement of its own arithmetic -- the six-operation form for reads
+    that pass the range test (all of them here: smooth insertion qualities), the seven-operation form when that is switched off:
+    any difference is a kernel bug, not rounding."""
     O = orc.oracle()
     rng = synth.rng_for(300)
     reads, haps = synth.make_region(rng, 9, 5, (20, 120), (30, 200), n_frac=0.02, unrelated_frac=0.2)
-    raw, _, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 45, A.ACCG_PHMM_FAST, want_log10=False)
+    assert all(O.orc_phmm_x6_eligible(len(r["b"]), r["i"], r["c"]) for r in reads)
+    for x6 in (True, False):
+        monkeypatch.setenv("ACCG_PHMM_X6", "1" if x6 else "0")
+        raw, _, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 45, A.ACCG_PHMM_FAST, want_log10=False)
+        k = 0
+        for r in reads:
+            for h in haps:
+                assert np.float32(_model(O, r, h, x6)).tobytes() == raw[k].tobytes(), (x6, k)
+                k += 1
+
+
+def test_fast_mixed_eligibility(ctx):
+    """Reads whose insertion qualities jump (1 -> 60 from one base to the next) fail the range test of the six-operation form
+    and run in the seven-operation one; a region mixes both kinds, every K class of 8- and 16-lane groups, and each read must
+    come out bit-equal to the model of the form it is eligible for."""
+    O = orc.oracle()
+    rng = synth.rng_for(302)
+    reads, haps = synth.make_region(rng, 40, 3, (16, 200), (40, 260), unrelated_frac=0.1)
+    for j, r in enumerate(reads):
+        if j % 3 == 0:
+            qi = np.frombuffer(r["i"], np.uint8).copy()
+            qi[::2] = 1; qi[1::2] = 60
+            r["i"] = qi.tobytes()
+    elig = [bool(O.orc_phmm_x6_eligible(len(r["b"]), r["i"], r["c"])) for r in reads]
+    assert any(elig) and not all(elig)
+    raw, l10, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 120, A.ACCG_PHMM_FAST)
     k = 0
-    for r in reads:
+    for r, e in zip(reads, elig):
         for h in haps:
-            assert np.float32(O.orc_phmm_forward_f32_fma(*orc.pair_args(r, h))).tobytes() == raw[k].tobytes(), k
+            assert np.float32(_model(O, r, h, e)).tobytes() == raw[k].tobytes(), (k, e)
             k += 1
+    _, want, _ = _oracle_region(reads, haps)
+    assert (np.abs(l10 - want) / np.abs(want)).max() < REL_TOL
 
 
 @pytest.mark.parametrize("rlen", [1, 2, 15, 16, 17, 31, 32, 47, 48, 63, 64, 79, 80, 95, 96, 111, 112, 127, 128, 143, 144,

@@ -109,3 +109,111 @@ def test_exact_reads_yield_one_full_length_seed():
     for r, o, k in zip(reads, out, num):
         spans = {(int(o[e][3]) >> 32, int(o[e][3]) & 0xFFFFFFFF) for e in range(k)}
         assert (0, len(r)) in spans
+
+
+# ---- the three passes from their definitions (no FM-index, no shared code): naive substring counts over genome + revcomp ----
+
+def _occ_table(text, read):
+    """occ[s][e] for every clean substring read[s:e] (ambiguous bases break it); None where it contains a base >= 4."""
+    t = text.tobytes()
+    n = len(read)
+    occ = {}
+    for s in range(n):
+        for e in range(s + 1, n + 1):
+            if read[e - 1] >= 4:
+                break
+            c = _count(text, read[s:e]) if (e - s <= 1 or occ.get((s, e - 1), 1) > 0) else 0
+            occ[(s, e)] = c
+            if c == 0:                       # longer ones have no occurrence either
+                for e2 in range(e + 1, n + 1):
+                    if read[e2 - 1] >= 4:
+                        break
+                    occ[(s, e2)] = 0
+                break
+    return occ
+
+
+def _smems_by_definition(occ, n, min_occ, must_cover=None):
+    """All substrings [s, e) with at least min_occ occurrences that cannot be extended by one base on either side without dropping
+    below min_occ (maximal exact matches), and that no other such match contains (super-maximal) -- optionally only those that
+    cover position must_cover, super-maximal among those."""
+    ok = lambda s, e: occ.get((s, e), 0) >= min_occ
+    mems = [(s, e) for (s, e) in occ if ok(s, e) and not ok(s - 1, e) and not ok(s, e + 1)
+            and (must_cover is None or s <= must_cover < e)]
+    return {(s, e) for (s, e) in mems if not any((s2 <= s and e <= e2) and (s2, e2) != (s, e) for (s2, e2) in mems)}
+
+
+def _passes(bwt, para, read):
+    O = orc.oracle()
+    out = np.zeros((512, 4), np.uint64)
+    bounds = (C.c_int * 3)()
+    seq = np.ascontiguousarray(read, np.uint8)
+    n = O.orc_smem_read_passes(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, len(read), 512, out.ctypes.data, bounds)
+    assert n <= 512
+    ent = [(int(o[3]) >> 32, int(o[3]) & 0xFFFFFFFF, int(o[2])) for o in out[:n]]
+    return ent[:bounds[0]], ent[bounds[0]:bounds[1]], ent[bounds[1]:bounds[2]]
+
+
+@pytest.mark.parametrize("seed,repeat", [(21, False), (22, True), (23, True), (24, True)])
+def test_pass1_is_the_set_of_smems_by_definition(seed, repeat):
+    """First pass of mem_collect_intv_new (bwt_smem1a_new from every position, baseline.cpp:394-400) = every super-maximal exact
+    match of at least 19 bases, each once, with its occurrence count on both strands."""
+    g, bwt, para, text, reads = _toy(seed, 3000, 25, (30, 120), repeat)
+    for r in reads:
+        occ = _occ_table(text, r)
+        want = {(s, e, occ[(s, e)]) for (s, e) in _smems_by_definition(occ, len(r), 1) if e - s >= 19}
+        p1, _, _ = _passes(bwt, para, r)
+        assert len(p1) == len(set(p1))                       # nothing reported twice
+        assert set(p1) == want, (sorted(p1), sorted(want))
+
+
+@pytest.mark.parametrize("seed", [25, 26, 27])
+def test_pass2_reseeds_inside_long_rare_smems(seed):
+    """Second pass (baseline.cpp:403-408): for every first-pass SMEM of at least 28 bases with at most 10 occurrences, the
+    super-maximal matches with MORE occurrences than it that cover its middle base, at least 19 bases long."""
+    g, bwt, para, text, reads = _toy(seed, 3000, 25, (60, 140), True)
+    seen_any = False
+    for r in reads:
+        occ = _occ_table(text, r)
+        p1, p2, _ = _passes(bwt, para, r)
+        want = []
+        for (s, e, o) in p1:
+            if e - s < 28 or o > 10:
+                continue
+            mid = (s + e) >> 1
+            for (s2, e2) in sorted(_smems_by_definition(occ, len(r), o + 1, must_cover=mid)):
+                if e2 - s2 >= 19:
+                    want.append((s2, e2, occ[(s2, e2)]))
+        assert sorted(p2) == sorted(want), (p1, p2, want)
+        seen_any |= bool(p2)
+    assert seen_any                                          # the planted repeats make the pass produce something
+
+
+@pytest.mark.parametrize("seed,repeat", [(28, False), (29, True)])
+def test_pass3_is_the_last_like_strategy_by_definition(seed, repeat):
+    """Third pass (bwt_seed_strategy1, baseline.cpp:306-327 from every restart point): from x, the first prefix read[x:i+1] of at
+    least 20 bases with fewer than 20 occurrences is reported if it occurs at all, and the scan restarts behind it; an ambiguous
+    base restarts the scan behind itself."""
+    g, bwt, para, text, reads = _toy(seed, 3000, 25, (30, 120), repeat)
+    for r in reads:
+        n = len(r)
+        want = []
+        x = 0
+        while x < n:
+            if r[x] >= 4:
+                x += 1
+                continue
+            nxt = n
+            for i in range(x + 1, n):
+                if r[i] >= 4:
+                    nxt = i + 1
+                    break
+                c = _count(text, r[x:i + 1])
+                if c < 20 and i - x >= 19:
+                    if c > 0:
+                        want.append((x, i + 1, c))
+                    nxt = i + 1
+                    break
+            x = nxt
+        _, _, p3 = _passes(bwt, para, r)
+        assert p3 == want, (p3, want)
