@@ -24,9 +24,12 @@ constexpr int phmm_slab_bytes(int K, int elem_bytes, bool compact) {
   return compact ? (K / 4) * 1024 + 64 * phmm_tail_stride(K) : phmm_qt(K, elem_bytes) * 1024;
 }
 constexpr bool phmm_is_compact(int elem_bytes, bool strict) { return elem_bytes == 4 && !strict; }
-constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16, bool compact = false) {
-  return (size_t)nchar * phmm_slab_bytes(K, elem_bytes, compact) + phmm_align16((size_t)(haps_cap + 1) * elem_bytes) +
-         phmm_align16((size_t)(2 * haps_cap + 3) * 4) + phmm_align16((size_t)2 * lpp + stream_cap + 24);
+// striped (reads longer than 64 x 16 - 1 bases): two carry arrays of one value per stream position behind the stream
+constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16, bool compact = false,
+                                bool striped = false) {
+  return (size_t)nchar * phmm_slab_bytes(K, elem_bytes, compact && !striped) + phmm_align16((size_t)(haps_cap + 1) * elem_bytes) +
+         phmm_align16((size_t)(2 * haps_cap + 3) * 4) + phmm_align16((size_t)2 * lpp + stream_cap + 24) +
+         (striped ? (size_t)2 * elem_bytes * (stream_cap + 2 * lpp + 24) : 0);
 }
 constexpr uint32_t PHMM_NO_READ = 0xFFFFFFFFu;
 
@@ -78,7 +81,7 @@ struct PhmmArgs {
 // (lanes per read, K) of the fp64 rescue kernels: 16 lanes x K for K in the list below, then (32,16) and (64,16).  Fine steps in K
 // matter here: an fp64 row costs twice the registers and ~1.8x the issue time of an fp32 one, so rows of padding are expensive.
 constexpr int PHMM_RESCUE_K16 = 11;
-constexpr int PHMM_RESCUE_CLASSES = PHMM_RESCUE_K16 + 2;
+constexpr int PHMM_RESCUE_CLASSES = PHMM_RESCUE_K16 + 3;      // ... (32,16), (64,16), (64,16) in stripes for reads of 1024 bases and more
 __host__ __device__ inline int phmm_rescue_k16(int i) {
   constexpr int ks[PHMM_RESCUE_K16] = {2, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16};
   return ks[i];
@@ -87,9 +90,10 @@ __host__ __device__ inline void phmm_rescue_shape(int cls, int* lpp, int* K) {
   if (cls < PHMM_RESCUE_K16) { *lpp = 16; *K = phmm_rescue_k16(cls); }
   else { *lpp = cls == PHMM_RESCUE_K16 ? 32 : 64; *K = 16; }
 }
+__host__ __device__ inline bool phmm_rescue_striped(int cls) { return cls == PHMM_RESCUE_K16 + 2; }
 __host__ __device__ inline void phmm_rescue_class(uint32_t len, int* cls, int* lpp, int* K) {
   const uint32_t rows = len + 1;
-  int c = PHMM_RESCUE_K16 + 1;
+  int c = rows <= 1024 ? PHMM_RESCUE_K16 + 1 : PHMM_RESCUE_K16 + 2;
   if (rows <= 256) { c = 0; while (16u * (uint32_t)phmm_rescue_k16(c) < rows) c++; }
   else if (rows <= 512) c = PHMM_RESCUE_K16;
   *cls = c;
@@ -114,9 +118,10 @@ hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hi
 // Launchers (phmm_kernel.hip). K = rows per lane, 1..PHMM_MAX_K.
 // a.stream_cap / a.haps_cap = largest haplotype stream (entries, bubbles included) / haplotype count among the jobs of this launch.
 constexpr int PHMM_K8_DEFAULT = 13;   // 8 lanes per read while the rows fit K <= 13 (beyond that the 2-wave occupancy costs more than it saves)
-void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);
+void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);        // reads of 1024 bases and more: (64, 16), swept in stripes
+inline bool phmm_striped(uint32_t read_len) { return read_len + 1 > 1024; }
 // x6 (fast mode only): the six-operation form of the sweep, for wavefronts all of whose reads pass phmm_x6_eligible()
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, bool striped, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 // The six-operation form keeps X divided by the row's pMX: Xs[r] = M[r-1] + c[r] Xs[r-1], c[r] = pXX[r] pMX[r-1] / pMX[r].
 // Xs is bounded by max(M) * F, F[r] = 1 + c[r] F[r-1]; M never exceeds INIT / H <= 2^120, so F <= 32 leaves a factor of 8 to
 // FLT_MAX.  Reads whose insertion qualities jump by more than ~7 dB from one base to the next push F up and stay in the
@@ -126,10 +131,10 @@ constexpr float PHMM_X6_MAX_F = 32.f;
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.
 // strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in
 // that order of every job that produced a result below PHMM_F64_TINY
-hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 constexpr double PHMM_F64_TINY = 1e-280;      // x 2^1020 scaling included: 28 decades above the smallest normal double
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
-hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 constexpr float PHMM_MIN_ACCEPTED = 1e-28f;   // host_type.h:21
 constexpr int PHMM_RESCUE_GRID = 4096;        // wavefronts per rescue launch (they stride over the device-side job count)
 

@@ -212,7 +212,7 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K, lpp; bool x6; uint32_t work0, n_work; int stream_cap, haps_cap; };
+struct KLaunch { int K, lpp; bool x6, striped; uint32_t work0, n_work; int stream_cap, haps_cap; };
 
 thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
 struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
@@ -382,7 +382,7 @@ void partition(accg_phmm_batch& b) {
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
   // read groups per region (one group = the reads of one wavefront), by descending read length so that they need the same K
-  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp; bool x6; };
+  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp; bool x6, striped; };
   const char* e6 = getenv("ACCG_PHMM_X6");                   // A/B knob: 0 = never use the six-operation form
   const bool allow_x6 = !(e6 && e6[0] == '0');
   const char* e8 = getenv("ACCG_PHMM_LPP8");                 // A/B knob: largest K run with 8 lanes per read (0 = never)
@@ -401,20 +401,22 @@ void partition(accg_phmm_batch& b) {
     for (uint32_t i = 0; i < r.n_reads;) {        // the longest read of a wavefront decides lanes per read and K
       Group Q;
       phmm_pick(b.rd[order[i]].len, &Q.lpp, &Q.K, max_k8);
+      Q.striped = phmm_striped(b.rd[order[i]].len);            // one read per wavefront either way (64 lanes)
       const uint32_t per = 64 / Q.lpp;
       // reads of at most 15 bases run in the reference's operation order even in fast mode (launch_f32), so they must not share
       // a wavefront with longer ones: a group stops at that boundary
       const bool first_tiny = b.rd[order[i]].len <= 15;
       // ... and a wavefront runs the six-operation form only if all of its reads pass the range test: a group stops where that changes
-      Q.x6 = allow_x6 && b.rd_x6[order[i]] != 0;
+      const bool elig0 = b.rd_x6[order[i]] != 0;               // the group takes reads of the first one's kind
+      Q.x6 = allow_x6 && elig0 && !Q.striped;
       uint32_t take = 0;
       for (uint32_t g = 0; g < PHMM_GROUPS; g++) {
         const bool ok = g < per && i + g < r.n_reads && take == g && (first_tiny || b.rd[order[i + g]].len > 15) &&
-                        (!allow_x6 || (b.rd_x6[order[i + g]] != 0) == Q.x6);
+                        (!allow_x6 || (b.rd_x6[order[i + g]] != 0) == elig0);
         Q.read[g] = ok ? order[i + g] : PHMM_NO_READ;
         take += ok;
       }
-      i += take;
+      i += take ? take : 1;                                    // (the first read always qualifies for its own group)
       groups[ri].push_back(Q);
       kw[Q.lpp == 8 ? 0 : Q.lpp == 16 ? 1 : Q.lpp == 32 ? 2 : 3][Q.K] += (uint64_t)r.n_haps;
     }
@@ -507,7 +509,7 @@ void partition(accg_phmm_batch& b) {
     }
   }
 
-  struct Job { PhmmWork w; int K, lpp; bool x6; uint64_t cost; uint32_t stream_len; };
+  struct Job { PhmmWork w; int K, lpp; bool x6, striped; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (groups[ri].empty()) continue;
@@ -535,19 +537,22 @@ void partition(accg_phmm_batch& b) {
       w.pad_[0] = w.pad_[1] = 0;
       for (size_t c = 0; c < runs.size(); c++) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
-        jobs.push_back({w, Q.K, Q.lpp, Q.x6, (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
+        const uint64_t stripes = Q.striped ? (b.rd[Q.read[0]].len + 1024) / 1024 : 1;
+        jobs.push_back({w, Q.K, Q.lpp, Q.x6, Q.striped, stripes * (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
       }
     }
   }
   // one launch per K; inside a launch the longest jobs go first so the tail is short
   std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
-    return x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.x6 != y.x6 ? x.x6 > y.x6 : x.cost > y.cost;
+    return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.x6 != y.x6 ? x.x6 > y.x6
+                                                                                                                                : x.cost > y.cost;
   });
   b.work.resize(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     b.work[i] = jobs[i].w;
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().x6 != jobs[i].x6)
-      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].x6, (uint32_t)i, 0, 0, 0});
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().x6 != jobs[i].x6 ||
+        b.launches.back().striped != jobs[i].striped)
+      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].x6, jobs[i].striped, (uint32_t)i, 0, 0, 0});
     KLaunch& L = b.launches.back();
     L.n_work++;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
@@ -589,7 +594,8 @@ int launch_f32(accg_phmm_batch* b, int mode) {
     // reference's float `log10f(x) - log10f(2^120)` has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
     // cleared: with them contracted the worst case over 1 500 random regions stays at that granularity, 2.4e-6.
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, l.x6 && !strict_l, a, l.work0, l.n_work, st));
+    if (l.striped) a.lds_min = 0;                   // one long read per wavefront and a large LDS block: nothing to pin
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, l.x6 && !strict_l, l.striped, a, l.work0, l.n_work, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -617,7 +623,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
     phmm_rescue_shape(c, &lpp_c, &k_c);
-    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, a, b->rescue_off[c], bound, st));
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -747,7 +753,7 @@ extern "C" int accg_phmm_batch_run_f64(accg_phmm_batch* b) {
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    ACCG_HIP(phmm_launch_f64(l.K, l.lpp, a, l.work0, l.n_work, b->ctx->stream));
+    ACCG_HIP(phmm_launch_f64(l.K, l.lpp, l.striped, a, l.work0, l.n_work, b->ctx->stream));
   }
   return ACCG_OK;
 }

@@ -108,9 +108,10 @@ __device__ __forceinline__ void load_dist(const unsigned char* tab_lane, unsigne
 
 // One column for every lane.  d[k] = dist of local row k against this lane's column.
 template <bool STRICT, int LPP, typename T, int K>
-__device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K]) {
+__device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K], bool carry_in = false, T ca = T(0), T cx = T(0)) {
   T a_in = group_shr1<LPP>(s.a_out);
   T x_in = group_shr1<LPP>(s.x_out);
+  if (carry_in) { a_in = ca; x_in = cx; }     // striped reads: lane 0 continues the row above, handed over by the previous stripe
   // pass 1: everything that reads the previous column's state
   s.a_out = diag_term<STRICT>(s.M[K - 1], s.X[K - 1], s.Y[K - 1], s.nMM, s.nGM);
   T Mn[K], Yn[K];
@@ -279,17 +280,20 @@ __device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& 
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false>
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false, bool STRIPED = false>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
-  constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT);
+  constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT) && !STRIPED;
   constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
   unsigned char* tab = smem;
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
   uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
   uint32_t* bpos = hcol + a.haps_cap + 1;
   uint8_t* stream = reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4);
+  // striped reads (more rows than a wavefront holds): what the last lane hands "to the right", per stream position, for the next stripe
+  T* carry_a = reinterpret_cast<T*>(stream + phmm_align16((size_t)2 * LPP + a.stream_cap + 24));
+  T* carry_x = carry_a + (a.stream_cap + 2 * LPP + 24);
 
   const int lane = threadIdx.x;
   constexpr int NG = 64 / LPP;              // reads per wavefront
@@ -340,10 +344,22 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   const int t_end = __builtin_amdgcn_readfirstlane(pos + LPP);         // the last lane passes the terminal bubble at pos+LPP-1
 
   // ---- per-row constants (registers) and the dist table (LDS) ---------------------------------
+  // A read of more than LPP * K - 1 bases (STRIPED, 64 lanes x 16 rows) is swept in stripes of LPP * K rows, top to bottom
+  // (the reference's CPU code does the same with its 8- or 4-row stripes and shiftOutM/X/Y, avx-pairhmm-template.h:224,265-297):
+  // stripe 0 holds the clone of row 0 and the first R - (stripes - 1) * LPP * K read rows, right-aligned as always; every further
+  // stripe is full.  The last lane's hand-off values go to carry_a / carry_x indexed by stream position, lane 0 of the next stripe
+  // takes them from there; only the last stripe sums up the last read row.
   Rows<T, K> s;
   const int R = (int)rr.len;
-  const int pad = LPP * K - R;              // >= 1 by construction of the job
   const uint8_t* rb = a.rblob + rr.off;
+  constexpr int SROWS = LPP * K;
+  const int n_stripes = STRIPED ? __builtin_amdgcn_readfirstlane((R + SROWS) / SROWS) : 1;
+  const int rows0 = R - (n_stripes - 1) * SROWS;                 // read rows in stripe 0 (0 .. SROWS - 1)
+  bool tiny = false;          // contracted fp64 rescue: a result close enough to the denormal range for the flush pattern to matter
+  for (int stripe = 0; stripe < n_stripes; stripe++) {
+  const bool last_stripe = stripe == n_stripes - 1;
+  const int pad = stripe == 0 ? SROWS - rows0 : 0;              // stripe 0: >= 1 by construction of the job
+  const int roff = stripe == 0 ? 0 : rows0 + (stripe - 1) * SROWS;   // read row (0-based) of the stripe's first non-clone flat row
   s.npad = pad - l * K;                     // clones are the first `pad` flat rows
   typedef typename Vec16<T>::type V;
 #pragma unroll
@@ -355,9 +371,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       const int k = q * VN + e;
       dM[e] = T(0); dX[e] = T(0); rbase[e] = CH_A;
       if (k < K) {
-        const int r = l * K + k - pad;          // 0-based read row, < 0: clone of row 0
+        const int r = roff + l * K + k - pad;   // 0-based read row, < roff (only in stripe 0: < 0): clone of row 0
         s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = T(0);
-        if (r >= 0) {
+        if (r >= roff) {
           const int qq = rb[R + r] & 127, qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
           const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
           s.pMM[k] = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];   // Context.h:163-174
@@ -392,8 +408,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     }
   }
   {
-    const int r = (l + 1) * K - pad;        // row 0 of the lane to the right
-    if (l < LPP - 1 && r >= 0) {
+    const int r = roff + (l + 1) * K - pad; // row 0 of the lane to the right (of the next stripe, for the last lane of a stripe that has one)
+    if ((l < LPP - 1 || !last_stripe) && r >= roff) {
       const int qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
       const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
       s.nMM = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];
@@ -440,10 +456,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   const uint8_t* hs = stream + LPP - 1 - l;           // hs[t] = this lane's column at step t (base index 0..4)
   const unsigned char* tab_lane = tab + lane * 16;
   int t = 0, jn = 0, jl = -1;
-  bool tiny = false;          // contracted fp64 rescue: a result close enough to the denormal range for the flush pattern to matter
   int nb = 0;                 // stream position of the next bubble lane 0 will meet
   unsigned long long rm = 0;  // bit i: lane i of every group is on a bubble this step
-  constexpr bool ASMCOL = !STRICT && sizeof(T) == 4;   // fp32 fast mode: column_f32_asm, dist values single-buffered
+  constexpr bool ASMCOL = !STRICT && sizeof(T) == 4 && !STRIPED;   // fp32 fast mode: column_f32_asm, dist values single-buffered
   unsigned o1 = hs[1];        // base index of step t+1 (loaded two steps ahead)
   if constexpr (ASMCOL) {
     // One loop, one call site of the column: the state registers then have a single life range set (a second copy of the
@@ -511,7 +526,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
   constexpr int U = 8;
   while (t < t_end) {
-    if (rm == 0 && nb - t >= U) {          // no lane is on a bubble for the next U steps
+    if (!STRIPED && rm == 0 && nb - t >= U) {          // no lane is on a bubble for the next U steps
 #pragma unroll
       for (int u = 0; u < U; u++) {
         T d[K];
@@ -532,15 +547,18 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     for (int k = 0; k < K; k++) d[k] = dn[k];
     load_dist<T, K>(tab_lane, o1 * SLAB, dn);
     o1 = hs[t + 2];
-    if (rm == 0) { column<STRICT, LPP>(s, d); t++; continue; }     // the last few columns in front of a bubble
+    T ca = T(0), cx = T(0);
+    const bool carry_in = STRIPED && stripe > 0 && l == 0;
+    if (carry_in) { ca = carry_a[t]; cx = carry_x[t]; }
+    if (!STRIPED && rm == 0) { column<STRICT, LPP>(s, d); t++; continue; }     // the last few columns in front of a bubble
     // Some lane (one per row of 16) is on a bubble = column 0 of its next haplotype.  Everybody runs the
     // ordinary column; that lane then overwrites its state with the column-0 border
     // (M = X = 0, Y = 0, clones of row 0: Y = INIT/H; baseline_impl.cpp:60-70) under EXEC.
     const bool rst = (rm >> l) & 1ull;
     T acc_done = s.acc;
-    column<STRICT, LPP>(s, d);
+    column<STRICT, LPP>(s, d, carry_in, ca, cx);
     if (rst) {
-      if (l == LPP - 1 && jl >= 0 && have) {                                         // haplotype jl is complete
+      if (l == LPP - 1 && jl >= 0 && have && last_stripe) {                          // haplotype jl is complete
         a.out[out_base + hcol[jl]] = acc_done;
         if (RESCUE && !STRICT && acc_done < (T)PHMM_F64_TINY) tiny = true;
         if (!RESCUE && sizeof(T) == 4 && a.read_flag && acc_done < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
@@ -556,12 +574,18 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       s.x_out = T(0);
       s.acc = T(0);
     }
+    if (STRIPED && !last_stripe && l == LPP - 1 && t >= LPP - 1) { carry_a[t - (LPP - 1)] = s.a_out; carry_x[t - (LPP - 1)] = s.x_out; }
     t++;
   }
+  if (STRIPED && !last_stripe) {            // the next stripe rebuilds the dist table this one read, and reads the carry this one wrote
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  }   // stripes
   return __any(tiny);
 }
 
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false>
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false, bool STRIPED = false>
 __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
   if (RESCUE && a.job_count) {
     // the number of jobs is only known on the device (phmm_rescue_plan); the grid is capped on the host and every wavefront
@@ -569,27 +593,34 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     // of one per potential job
     const uint32_t n = __builtin_amdgcn_readfirstlane(*a.job_count);
     for (uint32_t job = blockIdx.x; job < n; job += gridDim.x) {
-      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, X6>(a, work_base, job);
+      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, job);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next job rebuilds the LDS tables this one still read
       __builtin_amdgcn_wave_barrier();
       if (!STRICT && tiny) {
         // The contracted column is within 1e-8 of the reference's order as long as the result stays clear of the denormal
         // range; below PHMM_F64_TINY what gets flushed (x86 FTZ, matched on the device) depends on the last bits of every
         // intermediate and only the reference's own operation order reproduces compute_fp_avxd: redo the whole job that way.
-        phmm_job<T, K, LPP, true, RESCUE>(a, work_base, job, false);
+        phmm_job<T, K, LPP, true, RESCUE, false, STRIPED>(a, work_base, job, false);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
     }
   } else {
-    phmm_job<T, K, LPP, STRICT, RESCUE, X6>(a, work_base, blockIdx.x);
+    phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, blockIdx.x);
   }
 }
 
 template <typename T, bool STRICT, bool RESCUE, bool X6 = false>
-hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
+hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st, bool striped = false) {
   if (n_work == 0) return hipSuccess;
   dim3 grid(RESCUE && a.job_count ? (n_work < PHMM_RESCUE_GRID ? n_work : (uint32_t)PHMM_RESCUE_GRID) : n_work), block(64);
+  if (striped) {      // reads of 1024 bases and more: 64 lanes x 16 rows per stripe, the generic column
+    if (K != 16 || lpp != 64 || X6) return hipErrorInvalidValue;
+    size_t lds = phmm_lds_bytes(16, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, 64, false, true);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((phmm_kernel<T, 16, 64, STRICT, RESCUE, false, true>), grid, block, lds, st, a, work_base);
+    return hipGetLastError();
+  }
 #define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
     size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT)); \
@@ -685,21 +716,22 @@ hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hi
   return hipGetLastError();
 }
 
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, bool striped, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  if (striped) return strict ? launch<float, true, false>(K, lpp, a, wb, n, s, true) : launch<float, false, false>(K, lpp, a, wb, n, s, true);
   if (strict) return launch<float, true, false>(K, lpp, a, wb, n, s);
   return x6 ? launch<float, false, false, true>(K, lpp, a, wb, n, s) : launch<float, false, false, false>(K, lpp, a, wb, n, s);
 }
-hipError_t phmm_launch_f64(int K, int lpp, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, false>(K, lpp, a, wb, n, s);
+hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return launch<double, true, false>(K, lpp, a, wb, n, s, striped);
 }
-hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
   // strict: the reference's operation order throughout.  Otherwise the 7-op contraction of the fast mode, which is within 1e-8 of
   // it -- except where the fp64 likelihood x 2^1020 comes within ~1e28 of the smallest normal double: there, which values get
   // flushed (x86 FTZ, matched on the device) depends on the last bits of every intermediate, and a contracted result landed
   // 2.6e-5 away from compute_fp_avxd on log10 (the reference's own scalar baseline built with -mfma deviates by exactly as
   // much; found by tools/fuzz_phmm.py).  A job that produces such a result is redone in the reference's order by the same
   // wavefront (phmm_kernel), so the fast mode is bit-equal to the strict one for those pairs.
-  return strict ? launch<double, true, true>(K, lpp, a, wb, n, s) : launch<double, false, true>(K, lpp, a, wb, n, s);
+  return strict ? launch<double, true, true>(K, lpp, a, wb, n, s, striped) : launch<double, false, true>(K, lpp, a, wb, n, s, striped);
 }
 
 // (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support
@@ -714,7 +746,7 @@ void phmm_pick(uint32_t len, int* lpp, int* K, int max_k8) {
     const int need = (int)((rows + l - 1) / l);
     for (int k : ks) if (k >= need) { *lpp = l; *K = k; return; }
   }
-  *lpp = 64; *K = 0;
+  *lpp = 64; *K = 16;          // 1024 rows and more: striped (phmm_striped)
 }
 
 }  // namespace accg

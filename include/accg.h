@@ -33,7 +33,9 @@ enum {
   ACCG_ERR_NO_RCCL = -11         /* a communicator over more than one rank was asked for and librccl cannot be loaded */
 };
 
-#define ACCG_PHMM_MAX_READ 1023  /* rows held in registers: up to 64 lanes x 16 rows, one row reserved */
+#define ACCG_PHMM_MAX_READ 16383 /* up to 1023 bases a read's rows are held in registers (64 lanes x 16 rows, one row reserved); longer reads
+                                    are swept in stripes of 1024 rows, as the reference's CPU code does with its own stripe height
+                                    (pairhmm/xlnx/host/avx-pairhmm-template.h:224,265-297) */
 #define ACCG_PHMM_MAX_HAP 4000   /* one haplotype must fit the per-wave LDS stream */
 #define ACCG_SW_MAX_LEN 1535     /* htc-sw/host/common.h:13 MAX_SEQ_LENGTH - 1 */
 

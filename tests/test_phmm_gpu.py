@@ -114,13 +114,15 @@ def test_fast_mixed_eligibility(ctx):
 
 @pytest.mark.parametrize("rlen", [1, 2, 15, 16, 17, 31, 32, 47, 48, 63, 64, 79, 80, 95, 96, 111, 112, 127, 128, 143, 144,
                                   159, 160, 175, 176, 191, 192, 207, 208, 223, 224, 239, 240, 254, 255,
-                                  256, 287, 288, 300, 383, 384, 447, 448, 511, 512, 575, 576, 700, 895, 896, 1000, 1023])
+                                  256, 287, 288, 300, 383, 384, 447, 448, 511, 512, 575, 576, 700, 895, 896, 1000, 1023,
+                                  1024, 1025, 2046, 2047, 2048, 3100])
 def test_every_row_count_strict(ctx, rlen):
     """Every K class (rows per lane) and both sides of each K boundary, ragged haplotype lengths."""
     rng = synth.rng_for(1000 + rlen)
-    reads, haps = synth.make_region(rng, 5, 7, (max(1, rlen - 3), rlen), (1, 90) if rlen < 256 else (rlen, rlen + 60), n_frac=0.02, unrelated_frac=0.2)
+    nr, nh = (5, 7) if rlen < 1024 else (3, 3)          # 1024 and up: swept in stripes of 1024 rows
+    reads, haps = synth.make_region(rng, nr, nh, (max(1, rlen - 3), rlen), (1, 90) if rlen < 256 else (rlen, rlen + 60), n_frac=0.02, unrelated_frac=0.2)
     reads[0] = synth.make_read(rng, np.frombuffer(haps[0], np.uint8), rlen)
-    raw, l10, cnt = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 35, A.ACCG_PHMM_STRICT)
+    raw, l10, cnt = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), nr * nh, A.ACCG_PHMM_STRICT)
     oraw, ol10, oresc = _oracle_region(reads, haps)
     assert raw.tobytes() == oraw.tobytes()
     assert l10.tobytes() == ol10.tobytes()
@@ -200,7 +202,7 @@ def test_error_paths(ctx):
             (synth.serialize_reads([dict(b=b"ACXT", q=b"\x1e" * 4, i=b"\x28" * 4, d=b"\x28" * 4, c=b"\x0a" * 4)]), ok_h, -5),
             (ok_r, synth.serialize_haps([b"acgt"]), -5),
             (ok_r, synth.serialize_haps([b""]), -6),
-            (synth.serialize_reads([dict(b=b"A" * 1024, q=b"\x1e" * 1024, i=b"\x28" * 1024, d=b"\x28" * 1024, c=b"\x0a" * 1024)]), ok_h, -7),
+            (synth.serialize_reads([dict(b=b"A" * 16384, q=b"\x1e" * 16384, i=b"\x28" * 16384, d=b"\x28" * 16384, c=b"\x0a" * 16384)]), ok_h, -7),
             (ok_r, synth.serialize_haps([b"A" * 4001]), -7)):
         with pytest.raises(A.AccgError) as e:
             ctx.phmm_region(bad_r, bad_h, 1)

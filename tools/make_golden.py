@@ -90,9 +90,27 @@ def tables_fixture():
     print("tables")
 
 
+def striped_fixture():
+    """Reads of 1024 bases and more (swept in stripes of 1024 rows on the device): both sides of every stripe boundary, exact
+    reads (fp32 stays above the rescue threshold) and reads with substitutions (fp32 underflows, fp64 rescue)."""
+    rng = synth.rng_for(7)
+    template = synth.random_bases(rng, 3400)
+    haps = [synth.mutate(rng, template[o:o + hl], 0.005).tobytes() for o, hl in ((0, 3000), (200, 2800), (50, 3300))]
+    reads = []
+    for k, rl in enumerate((1024, 1025, 1500, 2047, 2048, 2049, 2600, 1023)):
+        r = synth.make_read(rng, np.frombuffer(haps[k % 3], np.uint8), rl, sub_rate=0.0 if k % 2 == 0 else 0.02)
+        if k % 2 == 0:
+            r["q"] = bytes([40] * rl); r["i"] = bytes([45] * rl); r["d"] = bytes([45] * rl)
+        reads.append(r)
+    phmm_fixture("phmm_striped", reads, haps)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     assert orc.ref_available(), "build oracle/_ref first: make -C oracle"
+    if len(sys.argv) > 1 and sys.argv[1] == "striped":
+        striped_fixture()
+        return
     tables_fixture()
     rng = synth.rng_for(0)   # C0 shape: 101 x 200, a 12 x 6 slice
     phmm_fixture("phmm_c0_slice", *synth.make_region(rng, 12, 6, 101, 200))
@@ -131,6 +149,7 @@ def main():
     lo_r = bases[rng.integers(0, 2, size=(24, 70))]; lo_a = bases[rng.integers(0, 2, size=(24, 55))]
     lo_r[:4] = ord("A"); lo_a[:2] = ord("A"); lo_a[2:4] = ord("C")
     sw_fixture("sw_low_complexity", lo_r, lo_a, MAXE=128)
+    striped_fixture()
 
 
 if __name__ == "__main__":
