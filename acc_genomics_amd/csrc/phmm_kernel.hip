@@ -315,16 +315,24 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   int pos = 0, n_haps = 0;
   unsigned n_flag = 0;
   for (int i = lane; i < LPP - 1; i += 64) stream[i] = 0;
+  // the haplotypes' descriptors, one per lane (a job lists at most PHMM_HAPS_MAX = 48): two latencies for all of them instead
+  // of two per haplotype
+  uint32_t gh_l = 0, col_l = 0, hoff_l = 0, hlen_l = 0;
+  if (lane < n_list) {
+    gh_l = a.hap_ids[hap_off + lane];
+    col_l = a.hp_local[gh_l];
+    const SeqRef h_ = a.hp[gh_l];
+    hoff_l = h_.off; hlen_l = h_.len;
+  }
   for (int j = 0; j < n_list; j++) {
-    const uint32_t gh = a.hap_ids[hap_off + j];
-    const uint32_t col = a.hp_local[gh];
+    const uint32_t col = __builtin_amdgcn_readlane(col_l, j);
     if (RESCUE) {   // keep this haplotype only if one of the wavefront's reads underflowed in fp32 against it
       const bool under = have && g < NG && l == 0 && a.raw[out_base + col] < PHMM_MIN_ACCEPTED;
       const unsigned long long m = __ballot(under);
       if (m == 0) continue;
       n_flag += (unsigned)__popcll(m);
     }
-    const SeqRef hr = a.hp[gh];
+    const SeqRef hr = {(uint32_t)__builtin_amdgcn_readlane(hoff_l, j), (uint32_t)__builtin_amdgcn_readlane(hlen_l, j)};
     if (lane == 0) {
       stream[LPP - 1 + pos] = 0;
       bpos[n_haps] = pos;
@@ -362,6 +370,32 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   const int roff = stripe == 0 ? 0 : rows0 + (stripe - 1) * SROWS;   // read row (0-based) of the stripe's first non-clone flat row
   s.npad = pad - l * K;                     // clones are the first `pad` flat rows
   typedef typename Vec16<T>::type V;
+  // Two batches of loads for the lane's K rows and row 0 of the lane to the right (index K): the five bytes of every row, then
+  // the table entries they select -- two memory latencies per job.  (With the loads inside "is this a read row?" branches,
+  // one row at a time, a job spent 26 dependent latencies here: a quarter of a wavefront's time on configs[1].)  Rows that are
+  // clones of row 0, or past the read, load a clamped row and are overruled below.
+  int vq[K + 1], vi[K + 1], vd[K + 1], vc[K + 1], vb[K + 1];
+  const int r_hi = R > 0 ? R - 1 : 0;
+#pragma unroll
+  for (int k = 0; k <= K; k++) {
+    int r = roff + l * K + k - pad;
+    r = r < 0 ? 0 : r > r_hi ? r_hi : r;
+    vb[k] = rb[r]; vq[k] = rb[R + r] & 127; vi[k] = rb[2 * R + r] & 127; vd[k] = rb[3 * R + r] & 127; vc[k] = rb[4 * R + r] & 127;
+  }
+  T tMM[K + 1], tGM[K + 1], tMX[K + 1], tXX[K + 1], tMY[K], tdM[K], tdX[K];
+#pragma unroll
+  for (int k = 0; k <= K; k++) {
+    const int lo = vi[k] < vd[k] ? vi[k] : vd[k], hi = vi[k] < vd[k] ? vd[k] : vi[k];
+    tMM[k] = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];   // Context.h:163-174
+    tGM[k] = a.tab.omph[vc[k]];                          // baseline_impl.cpp:54
+    tMX[k] = a.tab.ph[vi[k]];
+    tXX[k] = a.tab.ph[vc[k]];
+    if (k < K) {
+      tMY[k] = a.tab.ph[vd[k]];
+      tdM[k] = a.tab.omph[vq[k]];                        // baseline_impl.cpp:79-81
+      tdX[k] = a.tab.phd3[vq[k]];                        // baseline_impl.cpp:83
+    }
+  }
 #pragma unroll
   for (int q = 0; q < QT; q++) {
     T dM[VN], dX[VN];
@@ -372,22 +406,13 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       dM[e] = T(0); dX[e] = T(0); rbase[e] = CH_A;
       if (k < K) {
         const int r = roff + l * K + k - pad;   // 0-based read row, < roff (only in stripe 0: < 0): clone of row 0
+        const bool real = r >= roff;
         s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = T(0);
-        if (r >= roff) {
-          const int qq = rb[R + r] & 127, qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
-          const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
-          s.pMM[k] = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];   // Context.h:163-174
-          s.pGM[k] = a.tab.omph[qc];                            // baseline_impl.cpp:54
-          s.pMX[k] = a.tab.ph[qi];
-          s.pXX[k] = a.tab.ph[qc];
-          s.pMY[k] = a.tab.ph[qd];
-          dM[e] = a.tab.omph[qq];                               // baseline_impl.cpp:79-81
-          dX[e] = a.tab.phd3[qq];                               // baseline_impl.cpp:83
-          rbase[e] = char_index(rb[r]);
-        } else {
-          // clone of row 0: M stays 0 (dist = 0), X stays 0 (0*0 + 0*1), Y keeps INIT/H (0*0 + Y*1)
-          s.pMM[k] = T(0); s.pGM[k] = T(0); s.pMX[k] = T(0); s.pXX[k] = T(1); s.pMY[k] = T(0);
-        }
+        // clone of row 0: M stays 0 (dist = 0), X stays 0 (0*0 + 0*1), Y keeps INIT/H (0*0 + Y*1)
+        s.pMM[k] = real ? tMM[k] : T(0); s.pGM[k] = real ? tGM[k] : T(0); s.pMX[k] = real ? tMX[k] : T(0);
+        s.pXX[k] = real ? tXX[k] : T(1); s.pMY[k] = real ? tMY[k] : T(0);
+        dM[e] = real ? tdM[k] : T(0); dX[e] = real ? tdX[k] : T(0);
+        rbase[e] = real ? char_index((uint8_t)vb[k]) : CH_A;
       }
     }
     // dist table: one 16-byte vector per (hap base, row quad, lane)
@@ -409,14 +434,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   }
   {
     const int r = roff + (l + 1) * K - pad; // row 0 of the lane to the right (of the next stripe, for the last lane of a stripe that has one)
-    if ((l < LPP - 1 || !last_stripe) && r >= roff) {
-      const int qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
-      const int lo = qi < qd ? qi : qd, hi = qi < qd ? qd : qi;
-      s.nMM = a.tab.m2m[((hi * (hi + 1)) >> 1) + lo];
-      s.nGM = a.tab.omph[qc];
-      s.nMX = a.tab.ph[qi];
-      s.nXX = a.tab.ph[qc];
-    } else if (l == LPP - 1 && LPP != 32 && LPP != 8) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
+    if ((l < LPP - 1 || !last_stripe) && r >= roff) { s.nMM = tMM[K]; s.nGM = tGM[K]; s.nMX = tMX[K]; s.nXX = tXX[K]; }
+    else if (l == LPP - 1 && LPP != 32 && LPP != 8) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
     else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
   if (!STRICT) {

@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (fp32 VALU issue, no FMA double count)
 N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32
-PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8>"
+PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8,six-op column in gfx950 assembly>"
 SMEM_KERNEL_NAME = "smem_kernel<uint32_t>"
 
 
@@ -47,16 +47,18 @@ def traffic():
     return json.load(open(tr)) if os.path.exists(tr) else {}
 
 
-def valu_issue(insts_per_launch, k_ms, ubench_ns=None):
+def valu_issue(insts_per_launch, k_ms, ubench_ns=None, waves_per_simd=None):
     """VALU issue roof: wavefront VALU instructions of one launch (SQ_INSTS_VALU) spread over the chip's 1024 SIMDs at the
-    guide's 2 cycles per wave64 instruction and 2.4 GHz; `frac` = that ideal time / measured kernel time."""
+    guide's 2 cycles per wave64 instruction and 2.4 GHz; `frac` = that ideal time / measured kernel time.  `at_occupancy`
+    is the same with the rate tools/ubench2.hip measured for this instruction mix at the kernel's own resident waves per SIMD."""
     ideal_ms = insts_per_launch / N_SIMD * VALU_ISSUE_CYCLES / CLOCK_HZ * 1e3
     out = {"insts_per_launch": insts_per_launch, "cycles_per_inst": VALU_ISSUE_CYCLES, "clock_ghz": CLOCK_HZ / 1e9,
            "ideal_ms": ideal_ms, "frac": ideal_ms / k_ms}
     if ubench_ns:
         u_ms = insts_per_launch / N_SIMD * ubench_ns * 1e-6
-        out["ubench"] = {"ns_per_inst_per_simd_at_8_waves": ubench_ns, "ideal_ms": u_ms, "frac": u_ms / k_ms,
-                         "note": "tools/ubench.hip: what a saturated SIMD was measured to issue on this card"}
+        out["at_occupancy"] = {"waves_per_simd": waves_per_simd, "ns_per_inst_per_simd": ubench_ns, "ideal_ms": u_ms, "frac": u_ms / k_ms,
+                               "note": "profiles/r02_ubench2.txt: issue rate of this instruction mix at that many resident wavefronts "
+                                       "per SIMD (a wave64 instruction every 2 cycles needs 8 of them: 1.32 / 1.34 / 1.26 / 1.07 ns at 2 / 3 / 4 / 8)"}
     return out
 
 
@@ -216,7 +218,7 @@ def bench_sw(ctx, comm, steps, warmup, with_cpu):
                                "traffic": sw_traffic, "pmc": sw_tj.get("counters"), "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": b.algorithmic_bytes,
                                "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
-                                        "issue": valu_issue(sw_tj["valu_insts_per_launch"], k_ms, ubench_ns=1.78) if sw_tj.get("valu_insts_per_launch") else None,
+                                        "issue": valu_issue(sw_tj["valu_insts_per_launch"], k_ms, ubench_ns=1.78, waves_per_simd=8) if sw_tj.get("valu_insts_per_launch") else None,
                                         "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
                   "oracle_check": check,
                   "cpu_baseline": cpu_baseline_sw(refs, rl, alts, al) if with_cpu else None}
@@ -610,7 +612,7 @@ def main():
         roof["traffic"] = tj.get("hbm_bytes_per_launch")
         roof["pmc"] = tj.get("counters")             # rocprofv3 --pmc passes of the same workload (LDS bank conflicts among them)
         if tj.get("valu_insts_per_launch"):
-            roof["valu"]["issue"] = valu_issue(tj["valu_insts_per_launch"], k_ms, ubench_ns=1.04)
+            roof["valu"]["issue"] = valu_issue(tj["valu_insts_per_launch"], k_ms, ubench_ns=1.32, waves_per_simd=2)
         cpu = cpu_baseline_phmm(reads, haps) if with_cpu else None
         check = None
         if with_cpu:                                 # the measured batch against the oracle on a sample (checker only, untimed)

@@ -12,8 +12,10 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "pmc_%s_*" % tag, "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "phmm_kernel<float" in name:
-            k = "phmm_f32"
+        if "phmm_kernel<float, 13, 8" in name:
+            k = "phmm_f32"                  # the configs[1] kernel (the configs[3] leg also launches it for its 97-103-base reads)
+        elif "phmm_kernel<float" in name:
+            k = "phmm_f32_other"            # the other (lanes, K) classes of the configs[3] leg
         elif "phmm_kernel<double" in name:
             k = "phmm_rescue_f64"
         elif "bwasw_kernel" in name:
