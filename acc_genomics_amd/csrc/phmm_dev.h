@@ -19,11 +19,17 @@ constexpr size_t phmm_align16(size_t x) { return (x + 15) / 16 * 16; }
 // Bytes of one base's slab of the dist table.  General layout: QT 16-byte vectors per lane, quad q at q * 1024 + lane * 16.
 // fp32 fast kernels (`compact`): the K % 4 rows behind the last full quad take 4 (one row) or 8 (two rows) bytes per lane
 // instead of 16 -- at K = 13 that is 13 KB instead of 16 KB per wavefront, i.e. 11 instead of 9 resident wavefronts per CU.
-constexpr int phmm_tail_stride(int K) { return K % 4 == 1 ? 4 : K % 4 == 2 ? 8 : K % 4 == 3 ? 16 : 0; }
-constexpr int phmm_slab_bytes(int K, int elem_bytes, bool compact) {
-  return compact ? (K / 4) * 1024 + 64 * phmm_tail_stride(K) : phmm_qt(K, elem_bytes) * 1024;
+constexpr int phmm_tail_stride(int K, int elem_bytes = 4) {
+  return elem_bytes == 8 ? (K % 2 ? 8 : 0) : (K % 4 == 1 ? 4 : K % 4 == 2 ? 8 : K % 4 == 3 ? 16 : 0);
 }
-constexpr bool phmm_is_compact(int elem_bytes, bool strict) { return elem_bytes == 4 && !strict; }
+constexpr int phmm_slab_bytes(int K, int elem_bytes, bool compact) {
+  return compact ? (K / (16 / elem_bytes)) * 1024 + 64 * phmm_tail_stride(K, elem_bytes) : phmm_qt(K, elem_bytes) * 1024;
+}
+// Kernels whose column is written in assembly (phmm_kernel.hip) and use the compact slabs: the fast (contracted) arithmetic in fp32
+// for every K, in fp64 (the rescue pass) up to K = 10 -- beyond that an fp64 lane's 9 K register pairs do not fit the 256
+// architectural VGPRs an inline-assembly operand can live in.
+constexpr int PHMM_ASM_MAX_K_F64 = 10;
+constexpr bool phmm_is_compact(int elem_bytes, bool strict, int K = 1) { return !strict && (elem_bytes == 4 || K <= PHMM_ASM_MAX_K_F64); }
 // striped (reads longer than 64 x 16 - 1 bases): two carry arrays of one value per stream position behind the stream
 constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16, bool compact = false,
                                 bool striped = false) {
@@ -54,6 +60,7 @@ struct PhmmTables {
   T init;          // INITIAL_CONSTANT 2^120 | 2^1020  Context.h:109,149
 };
 
+constexpr uint32_t PHMM_RESCUE_GRID_DEFAULT = 4096;
 template <typename T>
 struct PhmmArgs {
   const uint8_t* rblob;       // concatenated wire-format read blobs
@@ -68,6 +75,10 @@ struct PhmmArgs {
   const float* raw;           // rescue pass only: the fp32 results that decide which pairs are redone
   unsigned long long* n_rescued;  // rescue pass only: count of (read, hap) pairs below the threshold
   const uint32_t* job_count;      // rescue pass only: number of valid jobs (device-side); blocks beyond it exit
+  const uint32_t* job_map;        // rescue pass, strict re-run of the jobs a fast launch listed: job index = job_map[i] (else null)
+  uint32_t* redo_count;           // rescue pass, fast mode: jobs that produced a result below PHMM_F64_TINY are appended to
+  uint32_t* redo_list;            //   redo_list (their index), counted in redo_count, and re-run in the strict form by a second launch
+  int is_redo;                    // that second launch: do not count the rescued pairs again
   uint32_t* read_flag;            // fp32 pass: set to 1 for a read with a result below MIN_ACCEPTED (nullable)
   PhmmTables<T> tab;
   int nchar;                  // 4 or 5 slabs in the dist table
@@ -131,11 +142,13 @@ constexpr float PHMM_X6_MAX_F = 32.f;
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.
 // strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in
 // that order of every job that produced a result below PHMM_F64_TINY
-hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s,
+                                  uint32_t grid_cap = PHMM_RESCUE_GRID_DEFAULT);
 constexpr double PHMM_F64_TINY = 1e-280;      // x 2^1020 scaling included: 28 decades above the smallest normal double
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
 hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 constexpr float PHMM_MIN_ACCEPTED = 1e-28f;   // host_type.h:21
 constexpr int PHMM_RESCUE_GRID = 4096;        // wavefronts per rescue launch (they stride over the device-side job count)
+constexpr int PHMM_REDO_GRID = 256;           // ... per strict re-run launch (nearly always nothing to do)
 
 }  // namespace accg

@@ -280,6 +280,7 @@ struct accg_phmm_batch {
   DevBuf<uint32_t> d_sorted_reads, d_flagged;
   DevBuf<uint32_t> d_state;   // zeroed per run: [n_reads] read flags, rescue job counts per class, [2] n_rescued (u64)
   DevBuf<PhmmWork> d_rescue_jobs;
+  DevBuf<uint32_t> d_redo;       // per rescue class (at rescue_off[c]): indices of the jobs to re-run in the strict form
   uint64_t last_kernel_ns = 0;
 };
 
@@ -562,7 +563,8 @@ void partition(accg_phmm_batch& b) {
 
 // layout of accg_phmm_batch::d_state (uint32 words)
 size_t state_counts(const accg_phmm_batch& b) { return (b.rd.size() + 1) / 2 * 2; }
-size_t state_nresc(const accg_phmm_batch& b) { return state_counts(b) + (PHMM_RESCUE_CLASSES + 3) / 2 * 2; }
+size_t state_redo(const accg_phmm_batch& b) { return state_counts(b) + PHMM_RESCUE_CLASSES; }     // jobs to redo in the strict form, per class
+size_t state_nresc(const accg_phmm_batch& b) { return state_counts(b) + (2 * PHMM_RESCUE_CLASSES + 3) / 2 * 2; }
 size_t state_words(const accg_phmm_batch& b) { return state_nresc(b) + 2; }
 
 template <typename T>
@@ -573,6 +575,7 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   a.raw = b.d_out.p; a.n_rescued = reinterpret_cast<unsigned long long*>(b.d_state.p + state_nresc(b)); a.tab = tab;
   a.read_flag = b.d_state.p;
   a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0; a.job_count = nullptr; a.lds_min = 0;
+  a.job_map = nullptr; a.redo_count = nullptr; a.redo_list = nullptr; a.is_redo = 0;
   return a;
 }
 
@@ -623,7 +626,16 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
     phmm_rescue_shape(c, &lpp_c, &k_c);
-    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, mode == ACCG_PHMM_STRICT, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st));
+    const bool strict = mode == ACCG_PHMM_STRICT;
+    a.job_map = nullptr; a.is_redo = 0;
+    a.redo_count = strict ? nullptr : b->d_state.p + state_redo(*b) + c;
+    a.redo_list = strict ? nullptr : b->d_redo.p + b->rescue_off[c];
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, strict, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st));
+    if (!strict) {        // the jobs that launch listed (results next to the denormal range), in the reference's operation order
+      PhmmArgs<double> r = a;
+      r.job_count = a.redo_count; r.job_map = a.redo_list; r.redo_count = nullptr; r.redo_list = nullptr; r.is_redo = 1;
+      ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, true, phmm_rescue_striped(c), r, b->rescue_off[c], bound, st, PHMM_REDO_GRID));
+    }
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   return ACCG_OK;
@@ -691,6 +703,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const size_t upload_bytes = off;
   const size_t o_flagged = take((b->rd.size() + 1) * sizeof(uint32_t));
   const size_t o_jobs = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(PhmmWork));
+  const size_t o_redo = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(uint32_t));
   const size_t o_out64 = take((b->pairs + 1) * sizeof(double));
   const size_t sw = state_words(*b);                         // even: the u64 counter at its end is 8-byte aligned
   const size_t o_state = take((sw + (sw & 1)) * sizeof(uint32_t) + (b->pairs + 1) * sizeof(float));
@@ -705,6 +718,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
   b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
   b->d_rescue_jobs.place(base, o_jobs, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
+  b->d_redo.place(base, o_redo, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
   b->d_out64.place(base, o_out64, b->pairs + 1);
   b->d_state.place(base, o_state, sw);
   b->d_out.place(base, o_out, b->pairs + 1);

@@ -278,13 +278,93 @@ __device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& 
   return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;   // 16 / 64 lanes: the last lane has nMX = nXX = 1, x_out = M + X
 }
 
+// ---- the same in fp64 (rescue pass, K <= PHMM_ASM_MAX_K_F64): register pairs, v_fma_f64 / v_mul_f64, seven operations per cell
+// in the order of column<false> (bit-identical results).  Compiled by hipcc the fp64 column needs 26 K + 26 registers: from K = 9
+// on that is more than the 256 architectural VGPRs, the rest goes through AGPR copies and one wavefront per SIMD is left; in place
+// it is 18 K + ~40, two wavefronts per SIMD at K = 10.  The lane shifts of 64-bit values stay with the compiler (two DPP moves each).
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <int K>
+struct DistRegsD {
+  static constexpr int FULL = K / 2, REM = K % 2, QT = (K + 1) / 2;
+  d2v q[FULL > 0 ? FULL : 1];
+  double tail;
+  __device__ __forceinline__ double get(int k) const { return k / 2 < FULL ? q[k / 2][k % 2] : tail; }
+  template <int Q> __device__ __forceinline__ void load(unsigned addr, unsigned tail_adj) {
+    if constexpr (Q < FULL) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[Q]) : "v"(addr), "n"(Q * 1024));
+    else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tail) : "v"(addr + tail_adj), "n"(Q * 1024));
+  }
+};
+template <int K, int... Q>
+__device__ __forceinline__ void load_all_quads(DistRegsD<K>& dq, unsigned addr, unsigned tail_adj, std::integer_sequence<int, Q...>) { (dq.template load<Q>(addr, tail_adj), ...); }
+
+template <int LPP, int K, int Q>
+__device__ __forceinline__ void column_rows_f64(Rows<double, K>& s, DistRegsD<K>& dq, unsigned addr_next, unsigned tail_adj, double a_in, double x_in,
+                                                double& tc, double& a_new) {
+  if constexpr (Q < DistRegsD<K>::QT) {
+    lgkm_wait<DistRegsD<K>::QT>();
+#pragma unroll
+    for (int k = 2 * Q; k < 2 * Q + 2 && k < K; k++) {
+      const double dk = dq.get(k);
+      const double gn = (k + 1 < K) ? s.pGM[k + 1] : s.nGM;
+      const double mn = (k + 1 < K) ? s.pMM[k + 1] : s.nMM;
+      double tn;
+      if (k == 0) {
+        asm volatile(
+            "v_fma_f64 %[tn], %[X], %[gn], %[Y]\n\t"
+            "v_mul_f64 %[Y], %[Y], %[xx]\n\t"
+            "v_fma_f64 %[tn], %[M], %[mn], %[tn]\n\t"
+            "v_fma_f64 %[Y], %[M], %[my], %[Y]\n\t"
+            "v_mul_f64 %[M], %[d], %[ai]"
+            : [tn] "=&v"(tn), [Y] "+v"(s.Y[0]), [M] "+v"(s.M[0])
+            : [X] "v"(s.X[0]), [gn] "v"(gn), [xx] "v"(s.pXX[0]), [mn] "v"(mn), [my] "v"(s.pMY[0]), [d] "v"(dk), [ai] "v"(a_in));
+        s.X[0] = x_in;
+      } else {
+        asm volatile(
+            "v_fma_f64 %[tn], %[X], %[gn], %[Y]\n\t"
+            "v_mul_f64 %[Y], %[Y], %[xx]\n\t"
+            "v_mul_f64 %[X], %[Xp], %[xx]\n\t"
+            "v_fma_f64 %[tn], %[M], %[mn], %[tn]\n\t"
+            "v_fma_f64 %[Y], %[M], %[my], %[Y]\n\t"
+            "v_fma_f64 %[X], %[Mp], %[mx], %[X]\n\t"
+            "v_mul_f64 %[M], %[d], %[tc]"
+            : [tn] "=&v"(tn), [X] "+v"(s.X[k]), [Y] "+v"(s.Y[k]), [M] "+v"(s.M[k])
+            : [gn] "v"(gn), [xx] "v"(s.pXX[k]), [mn] "v"(mn), [my] "v"(s.pMY[k]), [Xp] "v"(s.X[k - 1]), [Mp] "v"(s.M[k - 1]),
+              [mx] "v"(s.pMX[k]), [d] "v"(dk), [tc] "v"(tc));
+      }
+      if (k + 1 < K) tc = tn; else a_new = tn;
+    }
+    dq.template load<Q>(addr_next, tail_adj);
+    column_rows_f64<LPP, K, Q + 1>(s, dq, addr_next, tail_adj, a_in, x_in, tc, a_new);
+  }
+}
+template <int LPP, int K>
+__device__ __forceinline__ double column_f64_asm(Rows<double, K>& s, DistRegsD<K>& dq, unsigned addr_next, unsigned tail_adj) {
+  const double a_in = group_shr1<LPP>(s.a_out), x_in = group_shr1<LPP>(s.x_out);
+  double tc = 0.0, a_new = 0.0;
+  column_rows_f64<LPP, K, 0>(s, dq, addr_next, tail_adj, a_in, x_in, tc, a_new);
+  s.a_out = a_new;
+  s.x_out = fma_(s.M[K - 1], s.nMX, s.X[K - 1] * s.nXX);
+  return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;
+}
+
+// what the sweep needs to know about the assembly column of a value type
+template <typename T, int K> struct AsmCol;
+template <int K> struct AsmCol<float, K> {
+  typedef DistRegs<K> Regs;
+  template <int LPP, bool X6> static __device__ __forceinline__ float column(Rows<float, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f32_asm<LPP, K, X6>(s, dq, a, t); }
+};
+template <int K> struct AsmCol<double, K> {
+  typedef DistRegsD<K> Regs;
+  template <int LPP, bool X6> static __device__ __forceinline__ double column(Rows<double, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f64_asm<LPP, K>(s, dq, a, t); }
+};
+
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
 template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false, bool STRIPED = false>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
-  constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT) && !STRIPED;
+  constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT, K) && !STRIPED;
   constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
   unsigned char* tab = smem;
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
@@ -424,9 +504,11 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       for (int e = 0; e < VN; e++)   // rs == hap || rs == 'N' || hap == 'N'   (baseline_impl.cpp:80)
         v[e] = (c == CH_N || rbase[e] == CH_N || rbase[e] == c) ? dM[e] : dX[e];
       if constexpr (COMPACT) {
-        if (q < K / 4 || K % 4 == 3) *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
-        else if (K % 4 == 2) { typedef float V2 __attribute__((ext_vector_type(2))); *reinterpret_cast<V2*>(tab + c * SLAB + q * 1024 + lane * 8) = V2{(float)v[0], (float)v[1]}; }
-        else *reinterpret_cast<float*>(tab + c * SLAB + q * 1024 + lane * 4) = (float)v[0];
+        // full vectors at q * 1024 + lane * 16; the K % VN rows behind them packed at the tail stride (phmm_tail_stride)
+        constexpr int TS = phmm_tail_stride(K, (int)sizeof(T));
+        if (q < K / VN || TS == 16) *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
+        else if (TS == 8 && sizeof(T) == 4) { typedef float V2 __attribute__((ext_vector_type(2))); *reinterpret_cast<V2*>(tab + c * SLAB + q * 1024 + lane * 8) = V2{(float)v[0], (float)v[1]}; }
+        else *reinterpret_cast<T*>(tab + c * SLAB + q * 1024 + lane * TS) = v[0];
       } else {
         *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
       }
@@ -477,22 +559,23 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   int t = 0, jn = 0, jl = -1;
   int nb = 0;                 // stream position of the next bubble lane 0 will meet
   unsigned long long rm = 0;  // bit i: lane i of every group is on a bubble this step
-  constexpr bool ASMCOL = !STRICT && sizeof(T) == 4 && !STRIPED;   // fp32 fast mode: column_f32_asm, dist values single-buffered
+  constexpr bool ASMCOL = COMPACT;   // fast mode in fp32, and in fp64 up to K = 10: the column in assembly, dist values single-buffered
   unsigned o1 = hs[1];        // base index of step t+1 (loaded two steps ahead)
   if constexpr (ASMCOL) {
     // One loop, one call site of the column: the state registers then have a single life range set (a second copy of the
     // column for bubble-free runs made the register allocator keep two sets and shuffle between them).  Bubble bookkeeping is
     // scalar (rm, nb, jn live in SGPRs), so a bubble-free step pays a few SALU instructions for it.
-    DistRegs<K> dq;           // dist of step t; re-loaded for step t+1 quad by quad inside the column
+    typename AsmCol<T, K>::Regs dq;   // dist of step t; re-loaded for step t+1 quad by quad inside the column
+    constexpr int NLD = AsmCol<T, K>::Regs::QT;      // LDS loads of dist values per step
     const unsigned tab_a = lds_addr(tab_lane), hs_a = lds_addr(hs);
     const unsigned slab_s = __builtin_amdgcn_readfirstlane((int)SLAB);
-    const unsigned tail_adj = (unsigned)lane * (unsigned)(phmm_tail_stride(K) - 16);     // wraps: lane * stride - lane * 16
+    const unsigned tail_adj = (unsigned)lane * (unsigned)(phmm_tail_stride(K, (int)sizeof(T)) - 16);     // wraps: lane * stride - lane * 16
     unsigned o1n, addr_next;  // stream byte in flight; LDS address of the next step's slab for this lane
     {
       // step 0's values (its slab index read and awaited on the spot), then the steady-state order: U, L0 .. L(QT-1)
       asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_mad_u32_u24 %0, %0, %2, %3" : "=&v"(addr_next) : "v"(hs_a), "s"(slab_s), "v"(tab_a));
       asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(o1n) : "v"(hs_a));
-      load_all_quads<K>(dq, addr_next, tail_adj, std::make_integer_sequence<int, QT>{});
+      load_all_quads<K>(dq, addr_next, tail_adj, std::make_integer_sequence<int, NLD>{});
     }
     // U steps per loop iteration, in one straight line (a taken branch costs a wave some 30 cycles: with a loop back edge, a
     // bubble test and a "next bubble" test per step the single-step form of this loop lost 15 %).  The trip count is rounded up:
@@ -506,9 +589,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         rm = (rm << 1) & (LPP == 64 ? ~0ull : ((1ull << (LPP & 63)) - 1));
         if (__builtin_expect(t + u == nb, 0)) { rm |= 1ull; jn++; nb = __builtin_amdgcn_readfirstlane((int)bpos[jn]); }
         // the stream byte issued one step ago has landed: address of the next step's slab, next byte on its way
-        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "n"(QT));
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "n"(NLD));
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
-        float contrib = column_f32_asm<LPP, K, X6>(s, dq, addr_next, tail_adj);
+        T contrib = AsmCol<T, K>::template column<LPP, X6>(s, dq, addr_next, tail_adj);
         // Is any lane on a bubble?  Asked of the scalar unit through an opaque instruction: left to itself the compiler folds
         // this test into the per-lane one below and pays three vector instructions and an EXEC round trip on every step.
         unsigned any_bubble;
@@ -521,7 +604,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
           if ((rm >> l) & 1ull) {
             if (l == LPP - 1 && jl >= 0 && have) {                                       // haplotype jl is complete
               a.out[out_base + hcol[jl]] = s.acc;
-              if (!RESCUE && a.read_flag && s.acc < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
+              if (RESCUE && s.acc < (T)PHMM_F64_TINY) tiny = true;
+              if (!RESCUE && sizeof(T) == 4 && a.read_flag && s.acc < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
             }
             jl++;
             const T y0 = y0s[jl];
@@ -539,7 +623,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       }
       t += U;
     }
-    return false;
+    return __any(tiny);
   }
   T dn[K];                    // dist of step t (loaded one step ahead)
   load_dist<T, K>(tab_lane, hs[0] * SLAB, dn);
@@ -611,18 +695,16 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
     // walks the job array with the grid's stride, so a class with nothing to do costs a few hundred empty wavefronts instead
     // of one per potential job
     const uint32_t n = __builtin_amdgcn_readfirstlane(*a.job_count);
-    for (uint32_t job = blockIdx.x; job < n; job += gridDim.x) {
-      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, job);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+      const uint32_t job = a.job_map ? a.job_map[i] : i;
+      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, job, !a.is_redo);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next job rebuilds the LDS tables this one still read
       __builtin_amdgcn_wave_barrier();
-      if (!STRICT && tiny) {
-        // The contracted column is within 1e-8 of the reference's order as long as the result stays clear of the denormal
-        // range; below PHMM_F64_TINY what gets flushed (x86 FTZ, matched on the device) depends on the last bits of every
-        // intermediate and only the reference's own operation order reproduces compute_fp_avxd: redo the whole job that way.
-        phmm_job<T, K, LPP, true, RESCUE, false, STRIPED>(a, work_base, job, false);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
+      // The contracted column is within 1e-8 of the reference's order as long as the result stays clear of the denormal range;
+      // below PHMM_F64_TINY what gets flushed (x86 FTZ, matched on the device) depends on the last bits of every intermediate and
+      // only the reference's own operation order reproduces compute_fp_avxd: such a job is listed and redone that way by the
+      // launch that follows (a separate kernel: inlined here the strict column set this kernel's register count).
+      if (!STRICT && tiny && a.redo_count && threadIdx.x == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = job;
     }
   } else {
     phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, blockIdx.x);
@@ -630,9 +712,10 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
 }
 
 template <typename T, bool STRICT, bool RESCUE, bool X6 = false>
-hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st, bool striped = false) {
+hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st, bool striped = false,
+                  uint32_t grid_cap = PHMM_RESCUE_GRID) {
   if (n_work == 0) return hipSuccess;
-  dim3 grid(RESCUE && a.job_count ? (n_work < PHMM_RESCUE_GRID ? n_work : (uint32_t)PHMM_RESCUE_GRID) : n_work), block(64);
+  dim3 grid(RESCUE && a.job_count ? (n_work < grid_cap ? n_work : grid_cap) : n_work), block(64);
   if (striped) {      // reads of 1024 bases and more: 64 lanes x 16 rows per stripe, the generic column
     if (K != 16 || lpp != 64 || X6) return hipErrorInvalidValue;
     size_t lds = phmm_lds_bytes(16, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, 64, false, true);
@@ -642,7 +725,7 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
   }
 #define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
-    size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT)); \
+    size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT, KK)); \
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;                                                     \
     hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE, X6>), grid, block, lds, st, a, work_base);         \
   } break;
@@ -743,14 +826,15 @@ hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, bool striped, c
 hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
   return launch<double, true, false>(K, lpp, a, wb, n, s, striped);
 }
-hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s,
+                                  uint32_t grid_cap) {
   // strict: the reference's operation order throughout.  Otherwise the 7-op contraction of the fast mode, which is within 1e-8 of
   // it -- except where the fp64 likelihood x 2^1020 comes within ~1e28 of the smallest normal double: there, which values get
   // flushed (x86 FTZ, matched on the device) depends on the last bits of every intermediate, and a contracted result landed
   // 2.6e-5 away from compute_fp_avxd on log10 (the reference's own scalar baseline built with -mfma deviates by exactly as
   // much; found by tools/fuzz_phmm.py).  A job that produces such a result is redone in the reference's order by the same
   // wavefront (phmm_kernel), so the fast mode is bit-equal to the strict one for those pairs.
-  return strict ? launch<double, true, true>(K, lpp, a, wb, n, s, striped) : launch<double, false, true>(K, lpp, a, wb, n, s, striped);
+  return strict ? launch<double, true, true>(K, lpp, a, wb, n, s, striped, grid_cap) : launch<double, false, true>(K, lpp, a, wb, n, s, striped, grid_cap);
 }
 
 // (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support
