@@ -591,7 +591,9 @@ int launch_f32(accg_phmm_batch* b, int mode) {
     const bool strict_l = mode == ACCG_PHMM_STRICT || l.lpp * l.K <= 16;
     // pinned occupancy: the launch asks for as much LDS as leaves exactly 8, 16 or 32 of its wavefronts on a CU
     const int natural = waves_per_cu(l.K, a.nchar, l.stream_cap, l.haps_cap, l.lpp, strict_l);
-    const int wpc = b->force_wpc > 0 ? std::min(b->force_wpc, natural) : b->force_wpc < 0 ? natural : pinned_wpc(natural);
+    // (the compiled strict column is VOP3-heavy and does gain from a third wavefront per SIMD: any multiple of four for it)
+    const int wpc = b->force_wpc > 0 ? std::min(b->force_wpc, natural) : b->force_wpc < 0 ? natural
+                    : strict_l ? std::max(natural / 4 * 4, std::min(natural, 4)) : pinned_wpc(natural);
     a.lds_min = (int)((160 * 1024 / std::max(wpc, 1)) / 512 * 512);
     // Reads of at most 15 bases take the reference's operation order in fast mode too: their log10 is close to 0, where the
     // reference's float `log10f(x) - log10f(2^120)` has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show
