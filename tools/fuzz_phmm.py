@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised PairHMM parity run (GPU strict mode vs the oracle, bit for bit): random region shapes, read lengths 1..1023,
+"""Randomised PairHMM parity run (GPU strict mode vs the oracle, bit for bit): random region shapes, read lengths 1..3000 (1024 and
+up: swept in stripes),
 haplotype lengths 1..4000, N bases, extreme qualities.  usage: tools/fuzz_phmm.py [n_regions] [seed]"""
 import sys, os
 import numpy as np
@@ -17,13 +18,15 @@ worst_fast = 0.0
 worst_info = None
 with A.Context(0) as ctx:
     for it in range(n_regions):
-        kind = rng.integers(0, 5)
+        kind = rng.integers(0, 6)
         if kind == 0: rl = (1, int(rng.integers(1, 40))); hl = (1, int(rng.integers(1, 60)))
         elif kind == 1: rl = (int(rng.integers(20, 150)), int(rng.integers(150, 260))); hl = (int(rng.integers(1, 300)), int(rng.integers(300, 600)))
         elif kind == 2: rl = (int(rng.integers(250, 600)), int(rng.integers(600, 1024))); hl = (int(rng.integers(300, 1000)), int(rng.integers(1000, 2500)))
         elif kind == 3: rl = (int(rng.integers(1, 130)), int(rng.integers(130, 131))); hl = (3000, 4000)
-        else: rl = (int(rng.integers(560, 700)), int(rng.integers(700, 800))); hl = (int(rng.integers(800, 1200)), int(rng.integers(1200, 2400)))   # fp64 near 1e-300
+        elif kind == 4: rl = (int(rng.integers(560, 700)), int(rng.integers(700, 800))); hl = (int(rng.integers(800, 1200)), int(rng.integers(1200, 2400)))   # fp64 near 1e-300
+        else: rl = (int(rng.integers(900, 1100)), int(rng.integers(1100, 3000))); hl = (int(rng.integers(1100, 2000)), int(rng.integers(3000, 3400)))   # striped reads
         nr, nh = int(rng.integers(1, 24)), int(rng.integers(1, 9))
+        if kind == 5: nr, nh = int(rng.integers(1, 6)), int(rng.integers(1, 4))
         reads, haps = synth.make_region(rng, nr, nh, rl, hl, n_frac=float(rng.choice([0, 0.01, 0.2])), unrelated_frac=1.0 if kind == 4 else float(rng.choice([0, 0.3, 1.0])))
         if rng.random() < 0.3:        # extreme qualities
             for r in reads:
