@@ -25,7 +25,7 @@ constexpr int phmm_tail_stride(int K, int elem_bytes = 4) {
 constexpr int phmm_slab_bytes(int K, int elem_bytes, bool compact) {
   return compact ? (K / (16 / elem_bytes)) * 1024 + 64 * phmm_tail_stride(K, elem_bytes) : phmm_qt(K, elem_bytes) * 1024;
 }
-// Kernels whose column is written in assembly (phmm_kernel.hip) and use the compact slabs: the fast (contracted) arithmetic in fp32
+// Kernels whose column is written in assembly (phmm_kernel_impl.h) and use the compact slabs: the fast (contracted) arithmetic in fp32
 // for every K, in fp64 (the rescue pass) up to K = 10 -- beyond that an fp64 lane's 9 K register pairs do not fit the 256
 // architectural VGPRs an inline-assembly operand can live in.
 constexpr int PHMM_ASM_MAX_K_F64 = 10;
@@ -126,7 +126,7 @@ struct PhmmPlanArgs {
 };
 hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s);
 
-// Launchers (phmm_kernel.hip). K = rows per lane, 1..PHMM_MAX_K.
+// Launchers (phmm_kernel_impl.h). K = rows per lane, 1..PHMM_MAX_K.
 // a.stream_cap / a.haps_cap = largest haplotype stream (entries, bubbles included) / haplotype count among the jobs of this launch.
 constexpr int PHMM_K8_DEFAULT = 13;   // 8 lanes per read while the rows fit K <= 13 (beyond that the 2-wave occupancy costs more than it saves)
 void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);        // reads of 1024 bases and more: (64, 16), swept in stripes

@@ -1,0 +1,7 @@
+// fp32 fast-mode instantiations of the PairHMM kernel (column in assembly; seven- and six-operation forms).
+#include "phmm_kernel_impl.h"
+namespace accg {
+hipError_t phmm_launch_f32_fast(int K, int lpp, bool x6, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+  return x6 ? launch<float, false, false, true>(K, lpp, a, wb, n, s) : launch<float, false, false, false>(K, lpp, a, wb, n, s);
+}
+}  // namespace accg

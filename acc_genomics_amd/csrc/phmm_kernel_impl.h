@@ -1,4 +1,5 @@
-// PairHMM forward algorithm for gfx950 (MI355X), hand-written HIP.
+// PairHMM forward algorithm for gfx950 (MI355X), hand-written HIP: kernel templates, shared by the translation units that
+// instantiate them (phmm_kernel_fast.hip, phmm_kernel_strict.hip, phmm_kernel_f64.hip -- three, so that they build in parallel).
 //
 // What it computes: compute_full_prob_baseline<T> of the reference
 // (pairhmm/xlnx/host/baseline_impl.cpp:8-104; AVX twin avx-pairhmm-template.h:210-346), i.e. for one
@@ -31,6 +32,7 @@
 //     (slabs are multiples of 1 KiB apart, so the bank is decided by the lane alone).  Both LDS reads
 //     are software-pipelined one step ahead of their use.
 //   * no MFMA: the recurrence is a chain of fp32 mul/fma along the anti-diagonal, not a contraction.
+#pragma once
 #include "phmm_dev.h"
 #include <utility>
 
@@ -811,45 +813,4 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
 }
 
 }  // namespace
-
-hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s) {
-  if (n_regions == 0) return hipSuccess;
-  hipLaunchKernelGGL(phmm_rescue_plan, dim3(n_regions), dim3(256), 0, s, p);
-  return hipGetLastError();
-}
-
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, bool striped, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  if (striped) return strict ? launch<float, true, false>(K, lpp, a, wb, n, s, true) : launch<float, false, false>(K, lpp, a, wb, n, s, true);
-  if (strict) return launch<float, true, false>(K, lpp, a, wb, n, s);
-  return x6 ? launch<float, false, false, true>(K, lpp, a, wb, n, s) : launch<float, false, false, false>(K, lpp, a, wb, n, s);
-}
-hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s) {
-  return launch<double, true, false>(K, lpp, a, wb, n, s, striped);
-}
-hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s,
-                                  uint32_t grid_cap) {
-  // strict: the reference's operation order throughout.  Otherwise the 7-op contraction of the fast mode, which is within 1e-8 of
-  // it -- except where the fp64 likelihood x 2^1020 comes within ~1e28 of the smallest normal double: there, which values get
-  // flushed (x86 FTZ, matched on the device) depends on the last bits of every intermediate, and a contracted result landed
-  // 2.6e-5 away from compute_fp_avxd on log10 (the reference's own scalar baseline built with -mfma deviates by exactly as
-  // much; found by tools/fuzz_phmm.py).  A job that produces such a result is redone in the reference's order by the same
-  // wavefront (phmm_kernel), so the fast mode is bit-equal to the strict one for those pairs.
-  return strict ? launch<double, true, true>(K, lpp, a, wb, n, s, striped, grid_cap) : launch<double, false, true>(K, lpp, a, wb, n, s, striped, grid_cap);
-}
-
-// (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support
-void phmm_pick(uint32_t len, int* lpp, int* K, int max_k8) {
-  const uint32_t rows = len + 1;            // one row reserved as "row 0"
-  // 8 lanes per read: twice the rows per lane, so the per-step overhead (hand-off, stream and table reads) is spread
-  // over twice the cells, and the padding to a multiple of the lane count halves
-  if (rows <= 8u * (uint32_t)(max_k8 < PHMM_MAX_K ? max_k8 : PHMM_MAX_K)) { *lpp = 8; *K = (int)((rows + 7) / 8); return; }
-  if (rows <= 256) { *lpp = 16; *K = (int)((rows + 15) / 16); return; }
-  static const int ks[] = {9, 10, 12, 14, 16};
-  for (int l : {32, 64}) {
-    const int need = (int)((rows + l - 1) / l);
-    for (int k : ks) if (k >= need) { *lpp = l; *K = k; return; }
-  }
-  *lpp = 64; *K = 16;          // 1024 rows and more: striped (phmm_striped)
-}
-
 }  // namespace accg

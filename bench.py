@@ -524,6 +524,8 @@ def main():
     if world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d: reporting the %d ranks that are really running" % (args.gpus, world, world), file=sys.stderr)
     os.environ.setdefault("NCCL_DEBUG", "WARN")     # keeps RCCL's version banner off stdout: rank 0 prints ONE JSON line
+    if world > 1 and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")     # one node: RCCL's bootstrap sockets over loopback (no routable interface needed)
     share = os.environ.get("ACCG_BENCH_SHARE_GPU")  # rehearsal on a box with fewer GPUs than ranks: every rank on device 0,
     if share:                                       # counters through the file double (RCCL refuses two ranks on one device)
         os.environ.setdefault("ACCG_COMM_BACKEND", "file")

@@ -99,12 +99,12 @@ def test_entry_points_refuse_a_null_context():
 
 
 def test_hand_counted_lds_waits_hold_in_the_built_code():
-    """The fast PairHMM kernels issue and await their LDS loads by hand (phmm_kernel.hip, column_rows); tools/check_phmm_asm.py
+    """The fast PairHMM kernels issue and await their LDS loads by hand (phmm_kernel_impl.h, column_rows); tools/check_phmm_asm.py
     replays the built code object and fails if a register is touched while a ds_read is still writing it, or if a counted wait
     runs with a scalar load in flight."""
     import subprocess, sys
-    obj = os.path.join(ROOT, "acc_genomics_amd", "csrc", "build", "phmm_kernel.o")
-    if not os.path.exists(obj):
+    objs = [os.path.join(ROOT, "acc_genomics_amd", "csrc", "build", n) for n in ("phmm_kernel_fast.o", "phmm_kernel_f64.o")]
+    if not all(os.path.exists(o) for o in objs):
         pytest.skip("no build directory (prebuilt library only)")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_phmm_asm.py"), obj], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_phmm_asm.py")] + objs, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Checks the built PairHMM code object for the two things the hand-counted LDS waits of the fast sweep rely on
-(acc_genomics_amd/csrc/phmm_kernel.hip, column_rows): inside the sweep loop of every kernel whose column is written in assembly
+(acc_genomics_amd/csrc/phmm_kernel_impl.h, column_rows): inside the sweep loop of every kernel whose column is written in assembly
 
   * no counted `s_waitcnt lgkmcnt(N > 0)` while a scalar memory load is in flight: SMEM shares the lgkm counter with LDS and returns
     out of order, so the wait would no longer mean "all but my N youngest LDS operations";
@@ -9,7 +9,7 @@
     data (or be overwritten when the load lands).  The check replays every phmm kernel linearly with the hardware's rule (LDS
     operations return in order).
 
-usage: tools/check_phmm_asm.py [build/phmm_kernel.o]     (exit status 0 = clean)"""
+usage: tools/check_phmm_asm.py [object files]     default: build/phmm_kernel_fast.o build/phmm_kernel_f64.o     (exit status 0 = clean)"""
 import os
 import re
 import subprocess
@@ -97,9 +97,9 @@ def check_kernel(name, ins):
 
 
 def main():
-    obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "acc_genomics_amd", "csrc", "build", "phmm_kernel.o")
+    objs = sys.argv[1:] or [os.path.join(ROOT, "acc_genomics_amd", "csrc", "build", n) for n in ("phmm_kernel_fast.o", "phmm_kernel_f64.o")]
     bad, seen, hand = 0, 0, 0
-    for name, body in kernels(disassemble(obj)):
+    for name, body in (kb for obj in objs for kb in kernels(disassemble(obj))):
         if "phmm_kernel" not in name:
             continue
         ins = [l.split("//")[0].strip() for l in body if l and not l.startswith(";")]
