@@ -167,12 +167,26 @@ class FileComm:
         pass
 
 
-def open_comm(ctx, rank, world, backend=None):
-    """backend: "rccl" (default) or "file" (ACCG_COMM_BACKEND=file, directory = ACCG_COMM_FILE + ".d")."""
+def open_comm(ctx, rank, world, backend=None, allow_fallback=False):
+    """backend: "rccl" (default) or "file" (ACCG_COMM_BACKEND=file, directory = ACCG_COMM_FILE + ".d").
+
+    allow_fallback (bench.py only): if the RCCL communicator cannot be brought up (librccl missing, bootstrap refused), say so
+    loudly on stderr and reduce the counters through the file double instead, so that a multi-GPU run still yields its numbers;
+    the returned object's `backend` / `fallback_reason` tell which one ran.  The compute path is not involved either way."""
     backend = backend or os.environ.get("ACCG_COMM_BACKEND", "rccl")
     if backend == "file":
         return FileComm(ctx, rank, world, comm_file_default() + ".d")
-    return RcclComm(ctx, rank, world)
+    try:
+        return RcclComm(ctx, rank, world)
+    except Exception as e:                      # AccgError (ACCG_ERR_RCCL / ACCG_ERR_NO_RCCL), TimeoutError on the id file
+        if not allow_fallback or world == 1:
+            raise
+        import sys
+        print("acc_genomics_amd.dist: rank %d: RCCL communicator failed (%s); counters go through files in %s.d instead"
+              % (rank, e, comm_file_default()), file=sys.stderr)
+        c = FileComm(ctx, rank, world, comm_file_default() + ".d")
+        c.fallback_reason = str(e)
+        return c
 
 
 def gather_per_rank(comm, cells, pairs, kernel_ns, rescued, wall_s):

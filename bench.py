@@ -535,7 +535,7 @@ def main():
     from acc_genomics_amd import dist as D, synth
     mode = A.ACCG_PHMM_FAST if args.mode == "fast" else A.ACCG_PHMM_STRICT
     ctx = A.Context(dev)
-    comm = D.open_comm(ctx, rank, world)
+    comm = D.open_comm(ctx, rank, world, allow_fallback=True)
     with_cpu = not args.no_cpu_baseline
 
     reads, haps = make_c1(rank)
@@ -636,7 +636,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: PairHMM 2048 reads (101 bp) x 32 haplotypes (300 bp) = 65536 pairs per GPU, "
                                    "fp32 sweep + fp64 rescue pass, mode=%s" % args.mode,
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name,
-                       "collective": "rccl" if comm.uses_rccl else ("none (one rank)" if comm.world == 1 else comm.backend)},
+                       "collective": "rccl" if comm.uses_rccl else ("none (one rank)" if comm.world == 1 else
+                                      comm.backend + (" (RCCL failed: %s)" % comm.fallback_reason if getattr(comm, "fallback_reason", None) else ""))},
             "roofline": roof, "cpu_baseline": cpu, "oracle_check": check,
             "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
             "c3": c3, "sw": sw, "smem": smem, "bwasw": bwasw,
