@@ -6,6 +6,10 @@
 namespace accg {
 
 struct alignas(16) SmemIntv { uint64_t x0, x1, x2, info; };   // bwtintv_t: {x[0], x[1], x[2], info}
+// curr entries per read in the scratch: one bwt_smem1a_new call needs at most 256 (the fused kernel reuses them call by call); the
+// three-kernel path keeps the lists of all calls of the first pass, whose entries add up to at most twice the read length
+constexpr int SMEM_CURR_CAP = 512;
+constexpr int SMEM_SCRATCH_ENTRIES = SMEM_CURR_CAP + 256;
 
 struct SmemArgs {
   const uint32_t* bwt;          // BWA block layout, 64 B per 128 symbols (smem/host/baseline.cpp:26-37)
@@ -14,11 +18,15 @@ struct SmemArgs {
   const uint8_t* seq;           // n_reads x seq_stride codes (0-3, >= 4 ambiguous)
   const uint8_t* seq_len;
   uint32_t seq_stride, n_reads;
+  uint32_t read_words;          // LDS row per lane for its read: (longest read of the batch + 7) / 8 words, made odd
   SmemIntv* out;                // n_reads x max_out
   int32_t* mem_num;             // uncapped interval count per read
   uint32_t max_out;
-  SmemIntv* scratch;            // 2 x 256 intervals per thread, interleaved: element e of thread t at [e * n_threads + t]
+  SmemIntv* scratch;            // SMEM_SCRATCH_ENTRIES intervals per thread (curr lists, then the back list), interleaved: element e of thread t at [e * n_threads + t]
   uint32_t n_threads;
+  uint32_t* seg;                // three-kernel path: segment table of the first pass, 256 words per thread, interleaved the same way; null = the one-kernel form (default)
+  uint32_t* nseg;               //   ... segments per thread
+  uint32_t waves_per_cu;        // 0 = whatever fits; else an LDS request that admits this many wavefronts per CU
   uint32_t* queue;              // engine variant: next read of the launch (zeroed before it)
 };
 

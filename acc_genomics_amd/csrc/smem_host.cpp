@@ -24,10 +24,12 @@ struct accg_smem_batch {
   uint8_t *d_seq = nullptr, *d_len = nullptr;
   SmemIntv *d_out = nullptr, *d_scratch = nullptr;
   uint32_t* d_queue = nullptr;
+  uint32_t *d_seg = nullptr, *d_nseg = nullptr;   // three-kernel path: segment table of the first pass
   uint32_t engine_waves = 0;      // > 0: persistent-wavefront engine (smem_kernel.hip), compact index only
   int32_t* d_num = nullptr;
   uint64_t bases = 0;
-  ~accg_smem_batch() { for (void* p : {(void*)d_seq, (void*)d_len, (void*)d_out, (void*)d_num, (void*)d_scratch, (void*)d_queue}) if (p) hipFree(p); }
+  uint32_t longest = 0;         // longest read of the batch (sizes the kernels' LDS rows)
+  ~accg_smem_batch() { for (void* p : {(void*)d_seq, (void*)d_len, (void*)d_out, (void*)d_num, (void*)d_scratch, (void*)d_queue, (void*)d_seg, (void*)d_nseg}) if (p) hipFree(p); }
 };
 
 extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para,
@@ -49,7 +51,8 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
   for (int c = 0; c < 5; c++) x->L2[c] = bwt_para[1 + c];
   // BWA's block (64 B per 128 symbols: 4 x u64 cumulative counts + 8 x 16 symbols) costs a lookup four 16-byte loads and
   // eight words of popcounts.  While the counts fit 32 bits the index is re-laid-out on upload into half-blocks of the
-  // same total size, 32 B per 64 symbols = 4 x u32 counts + 4 x 16 symbols: one sector, two loads, four words per lookup.
+  // same total size, 32 B per 64 symbols = 4 x u32 counts + the symbols' low and high bits as two 64-bit planes: one sector, two
+  // loads, three masked popcounts per lookup.
   // The counts a lookup returns are the same numbers.  ACCG_SMEM_COMPACT=0 keeps the caller's layout.
   const uint64_t n_blocks = bwt_words / 16;
   const char* ec = getenv("ACCG_SMEM_COMPACT");
@@ -64,16 +67,21 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
       uint32_t* d1 = d0 + 8;
       uint32_t c[4];
       for (int s = 0; s < 4; s++) c[s] = src[2 * s];              // low words of the u64 counts (high words are 0 here)
-      for (int s = 0; s < 4; s++) d0[s] = c[s];
-      for (int j = 0; j < 4; j++) {
-        const uint32_t v = src[8 + j];
-        d0[4 + j] = v;
-        const uint32_t lo = v & 0x55555555u, hi = (v >> 1) & 0x55555555u;
-        const uint32_t n1 = __builtin_popcount(lo & ~hi), n2 = __builtin_popcount(hi & ~lo), n3 = __builtin_popcount(hi & lo);
-        c[1] += n1; c[2] += n2; c[3] += n3; c[0] += 16 - n1 - n2 - n3;
+      for (int half = 0; half < 2; half++) {
+        uint32_t* d = half ? d1 : d0;
+        for (int s = 0; s < 4; s++) d[s] = c[s];
+        uint64_t lo = 0, hi = 0;                                   // bit planes: symbol p of the half-block at bit p
+        for (int j = 0; j < 4; j++) {
+          const uint32_t v = src[8 + 4 * half + j];                // 16 symbols, first in the top bits
+          for (int e = 0; e < 16; e++) {
+            const uint32_t sym = (v >> (30 - 2 * e)) & 3u;
+            lo |= (uint64_t)(sym & 1u) << (16 * j + e);
+            hi |= (uint64_t)(sym >> 1) << (16 * j + e);
+            c[sym]++;
+          }
+        }
+        d[4] = (uint32_t)lo; d[5] = (uint32_t)(lo >> 32); d[6] = (uint32_t)hi; d[7] = (uint32_t)(hi >> 32);
       }
-      for (int s = 0; s < 4; s++) d1[s] = c[s];
-      for (int j = 0; j < 4; j++) d1[4 + j] = src[12 + j];
     }
     ACCG_HIP(hipMemcpy(x->d_bwt, cb.data(), bwt_words * 4, hipMemcpyHostToDevice));
   } else {
@@ -97,7 +105,7 @@ extern "C" int accg_smem_batch_create(accg_smem_index* idx, const uint8_t* seq, 
   ACCG_HIP(hipSetDevice(idx->ctx->device));
   std::unique_ptr<accg_smem_batch> b(new accg_smem_batch);
   b->idx = idx; b->n = n_reads; b->stride = seq_stride; b->max_out = max_out;
-  // Reads of one launch: each holds 512 interval records of scratch (16 B with 32-bit bounds, 32 B otherwise), i.e. 8.6 GB
+  // Reads of one launch: each holds 768 interval records of scratch (16 B with 32-bit bounds, 32 B otherwise), i.e. 12.9 GB
   // for 2^20 reads -- small change out of 288 GB, and one big launch beats several smaller ones (every launch ends in a tail
   // of the few wavefronts whose reads took longest: 21.5 ms in four launches, 17.5 ms in one, for 2^20 reads).
   uint32_t max_slice = idx->compact ? (1u << 20) : (1u << 19);
@@ -118,11 +126,18 @@ extern "C" int accg_smem_batch_create(accg_smem_index* idx, const uint8_t* seq, 
   ACCG_HIP(hipMalloc((void**)&b->d_len, n1));
   ACCG_HIP(hipMalloc((void**)&b->d_out, n1 * max_out * sizeof(SmemIntv)));
   ACCG_HIP(hipMalloc((void**)&b->d_num, n1 * sizeof(int32_t)));
-  ACCG_HIP(hipMalloc((void**)&b->d_scratch, (size_t)b->slice * 512 * (idx->compact ? 16 : sizeof(SmemIntv))));
+  ACCG_HIP(hipMalloc((void**)&b->d_scratch, (size_t)b->slice * SMEM_SCRATCH_ENTRIES * (idx->compact ? 16 : sizeof(SmemIntv))));
+  {
+    const char* es = getenv("ACCG_SMEM_SPLIT");        // A/B knob: 1 = the three-kernel form (smem_kernel.hip; slower)
+    if (es && es[0] == '1' && !b->engine_waves) {
+      ACCG_HIP(hipMalloc((void**)&b->d_seg, (size_t)b->slice * 256 * sizeof(uint32_t)));
+      ACCG_HIP(hipMalloc((void**)&b->d_nseg, (size_t)b->slice * sizeof(uint32_t)));
+    }
+  }
   if (n_reads) {
     ACCG_HIP(hipMemcpy(b->d_seq, seq, (size_t)n_reads * seq_stride, hipMemcpyHostToDevice));
     ACCG_HIP(hipMemcpy(b->d_len, seq_len, n_reads, hipMemcpyHostToDevice));
-    for (uint32_t i = 0; i < n_reads; i++) b->bases += seq_len[i];
+    for (uint32_t i = 0; i < n_reads; i++) { b->bases += seq_len[i]; b->longest = std::max<uint32_t>(b->longest, seq_len[i]); }
   }
   *out = b.release();
   return ACCG_OK;
@@ -138,6 +153,11 @@ extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
   for (int c = 0; c < 5; c++) a.L2[c] = x->L2[c];
   a.seq = b->d_seq; a.seq_len = b->d_len; a.seq_stride = b->stride; a.n_reads = b->n;
   a.out = b->d_out; a.mem_num = b->d_num; a.max_out = b->max_out; a.scratch = b->d_scratch; a.n_threads = b->slice;
+  a.seg = b->d_seg; a.nseg = b->d_nseg;
+  a.read_words = ((b->longest + 7) / 8) | 1u;
+  // wavefronts per CU (by an LDS request): the fused kernel fits 32 at its 63 VGPRs and measures best at 24 (13.5 against 13.8 ms on
+  // configs[4]); the split form picks per kernel (smem_launch).  ACCG_SMEM_WPC overrides, 0 = no limit.
+  { const char* e = getenv("ACCG_SMEM_WPC"); a.waves_per_cu = e ? (uint32_t)atoi(e) : (b->d_seg ? 0u : 24u); }
   if (b->engine_waves) {
     a.queue = b->d_queue;
     ACCG_HIP(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), x->ctx->stream));

@@ -16,6 +16,7 @@
 // when the index has fewer than 2^32 symbols (smem_host.cpp) -- then every interval bound fits 32 bits, the interval record
 // is 16 bytes instead of 32 and the kernel needs about half the registers (more reads in flight per CU).
 #include <stdlib.h>
+#include <algorithm>
 #include "smem_dev.h"
 
 namespace accg {
@@ -78,32 +79,29 @@ __device__ __forceinline__ void occ4(const Ctx<uint64_t>& f, uint64_t k, uint64_
 __device__ __forceinline__ void occ4_2(const Ctx<uint64_t>& f, uint64_t k, uint64_t l, uint64_t tk[4], uint64_t tl[4]) {
   occ4(f, k, tk); occ4(f, l, tl);
 }
-// ... over the half-block layout: 32 B per 64 symbols = 4 x u32 counts + 4 words.  When k and l fall into one half-block
-// (the usual case once the interval is narrower than a block) it is fetched once; lanes that do need a second one fetch it
-// under EXEC.
+// ... over the half-block layout: 32 B per 64 symbols = 4 x u32 counts + the 64 symbols as two bit planes (low bits, high bits;
+// symbol p of the half-block at bit p).  A count up to position r is then three masked 64-bit popcounts -- a quarter of the
+// integer work of the 2-bit words above, and this kernel's backward halves are bound by instruction issue.
+// When k and l fall into one half-block (the usual case once the interval is narrower than a block) it is fetched once; lanes
+// that do need a second one fetch it under EXEC.
+__device__ __forceinline__ void count_planes(const uint4 h, const uint4 pl, uint32_t r, uint32_t cnt[4]) {
+  const uint64_t m = ~0ull >> (63u - r);
+  const uint64_t lo = (((uint64_t)pl.y << 32) | pl.x) & m, hi = (((uint64_t)pl.w << 32) | pl.z) & m;
+  const uint32_t c1 = (uint32_t)__popcll(lo & ~hi), c2 = (uint32_t)__popcll(hi & ~lo), c3 = (uint32_t)__popcll(hi & lo);
+  cnt[1] = h.y + c1; cnt[2] = h.z + c2; cnt[3] = h.w + c3; cnt[0] = h.x + (r + 1u) - c1 - c2 - c3;
+}
+// bwt_occ4's k == -1 case (:19) cannot occur here and is not tested for: every interval bound this kernel holds is >= 1
+// (set_intv1 starts at L2[c] + 1, bwt_extend yields L2[b] + 1 + count and other-strand bound + non-negative terms), so k = bound - 1 >= 0.
 __device__ __forceinline__ void occ4_2(const Ctx<uint32_t>& f, uint32_t k, uint32_t l, uint32_t tk[4], uint32_t tl[4]) {
-  const bool k_none = k == (uint32_t)-1, l_none = l == (uint32_t)-1;
   k -= (k >= f.primary); l -= (l >= f.primary);
-  if (k_none) k = 0;
-  if (l_none) l = 0;
   const uint4* bk = reinterpret_cast<const uint4*>(f.bwt + ((k >> 6) << 3));
-  uint4 h = bk[0], w4 = bk[1];
-  {
-    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-    tk[0] = h.x; tk[1] = h.y; tk[2] = h.z; tk[3] = h.w;
-    count_words<4>(w, (int)(k & 63), tk);
-  }
+  uint4 h = bk[0], pl = bk[1];
+  count_planes(h, pl, k & 63u, tk);
   if ((k >> 6) != (l >> 6)) {
     const uint4* bl = reinterpret_cast<const uint4*>(f.bwt + ((l >> 6) << 3));
-    h = bl[0]; w4 = bl[1];
+    h = bl[0]; pl = bl[1];
   }
-  {
-    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-    tl[0] = h.x; tl[1] = h.y; tl[2] = h.z; tl[3] = h.w;
-    count_words<4>(w, (int)(l & 63), tl);
-  }
-  if (k_none) tk[0] = tk[1] = tk[2] = tk[3] = 0;
-  if (l_none) tl[0] = tl[1] = tl[2] = tl[3] = 0;
+  count_planes(h, pl, l & 63u, tl);
 }
 
 // bwt_extend (baseline.cpp:87-100), returning only the interval of base c; x[is_back ? 0 : 1] is the strand that is looked up
@@ -138,10 +136,11 @@ __device__ __forceinline__ Intv<IT> set_intv1(const Ctx<IT>& f, int c) {      //
 }
 
 template <typename IT>
-struct Lists {            // thread-interleaved scratch
+struct Lists {            // thread-interleaved scratch: SMEM_CURR_CAP curr entries, then 256 back entries
   Intv<IT>* base; uint32_t stride;
-  __device__ __forceinline__ Intv<IT>& curr(int e) const { return base[(size_t)e * stride]; }
-  __device__ __forceinline__ Intv<IT>& back(int e) const { return base[(size_t)(256 + e) * stride]; }
+  int curr0;              // first curr entry of the bwt_smem1a_new call in progress (the split path keeps every call's list)
+  __device__ __forceinline__ Intv<IT>& curr(int e) const { return base[(size_t)(curr0 + e) * stride]; }
+  __device__ __forceinline__ Intv<IT>& back(int e) const { return base[(size_t)(SMEM_CURR_CAP + e) * stride]; }
 };
 
 struct Out {
@@ -153,17 +152,39 @@ struct Out {
   }
 };
 
-// bwt_smem1a_new (baseline.cpp:180-304), max_intv = 0
-template <typename IT>
-__device__ int smem1a_new(const Ctx<IT>& f, int len, const uint8_t* q, int x, int min_intv, Out& mem, const Lists<IT>& L) {
+// The lane's read, 4 bits per base, in LDS (a row of a.read_words words per lane -- the batch's longest read rounded up to an odd
+// number of words, so that the lanes of a wavefront spread over the banks; dynamic LDS: 150-base reads take 4.9 KB per wavefront).  Read straight from global memory every q[i] is a byte load from the lane's own 128-byte line: 64 lines per wave
+// instruction, no reuse that the L1 could hold on to (24 wavefronts x 64 reads x 128 B per CU) -- on configs[4] that was 20 GB
+// of line traffic per launch for 150 MB of bases, on top of the index lookups.
+struct ReadLds {
+  const uint32_t* w;
+  __device__ __forceinline__ int operator[](int i) const { return (int)((w[i >> 3] >> ((i & 7) << 2)) & 0xFu); }
+};
+__device__ __forceinline__ ReadLds stage_read(uint32_t* s_read, uint32_t row_words, const uint8_t* src, int len) {
+  uint32_t* my = s_read + threadIdx.x * row_words;
+  for (int w8 = 0; w8 * 8 < len; w8++) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int pos = w8 * 8 + e;
+      const uint32_t c = pos < len ? src[pos] : 4u;
+      packed |= (c > 4u ? 4u : c) << (e << 2);
+    }
+    my[w8] = packed;
+  }
+  return ReadLds{my};
+}
+
+// bwt_smem1a_new (baseline.cpp:180-304), max_intv = 0, in its two halves.
+// Forward half (:193-218): extends q[x..] to the right, L.curr(0 .. n_curr) receives the interval in front of every change of
+// size; returns n_curr, *ret = where the next call of the first pass starts.
+template <typename IT, typename Q>
+__device__ __forceinline__ int smem1a_fwd(const Ctx<IT>& f, int len, const Q& q, int x, int min_intv, const Lists<IT>& L, int* ret) {
   typedef Intv<IT> I;
-  I ik, temp;
-  if (q[x] > 3) return x + 1;
   if (min_intv < 1) min_intv = 1;
-  temp.x0 = temp.x1 = temp.x2 = 0; temp.set(0, 0);
-  ik = set_intv1(f, q[x]);
+  I ik = set_intv1(f, q[x]);
   ik.set((uint32_t)(x + 1), 0);
-  int n_curr = 0, n_back = 0, i;
+  int n_curr = 0, i;
   for (i = x + 1; i < len; i++) {
     if (q[i] < 4) {
       const I nx = extend(f, ik, false, 3 - q[i]);
@@ -172,7 +193,17 @@ __device__ int smem1a_new(const Ctx<IT>& f, int len, const uint8_t* q, int x, in
     } else { L.curr(n_curr++) = ik; break; }
   }
   if (i == len) L.curr(n_curr++) = ik;
-  const int ret = (int)L.curr(n_curr - 1).lo();
+  *ret = (int)L.curr(n_curr - 1).lo();
+  return n_curr;
+}
+// Backward half (:219-299): over the n_curr entries of L.curr
+template <typename IT, typename Q>
+__device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int min_intv, Out& mem, const Lists<IT>& L, int n_curr) {
+  typedef Intv<IT> I;
+  I ik, temp;
+  if (min_intv < 1) min_intv = 1;
+  temp.x0 = temp.x1 = temp.x2 = 0; temp.set(0, 0);
+  int n_back = 0, i;
   int start = x, stop = x, max_len = 0;
   i = 0;
   while (i < n_curr) {
@@ -221,12 +252,19 @@ __device__ int smem1a_new(const Ctx<IT>& f, int len, const uint8_t* q, int x, in
     }
     if (i >= n_curr && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
   }
+}
+template <typename IT, typename Q>
+__device__ int smem1a_new(const Ctx<IT>& f, int len, const Q& q, int x, int min_intv, Out& mem, const Lists<IT>& L) {
+  if (q[x] > 3) return x + 1;
+  int ret;
+  const int n_curr = smem1a_fwd(f, len, q, x, min_intv, L, &ret);
+  smem1a_back(f, len, q, x, min_intv, mem, L, n_curr);
   return ret;
 }
 
 // bwt_seed_strategy1 (baseline.cpp:306-327)
-template <typename IT>
-__device__ int seed_strategy1(const Ctx<IT>& f, int len, const uint8_t* q, int x, int min_len, int max_intv, Intv<IT>& mem) {
+template <typename IT, typename Q>
+__device__ int seed_strategy1(const Ctx<IT>& f, int len, const Q& q, int x, int min_len, int max_intv, Intv<IT>& mem) {
   Intv<IT> ik;
   mem.x0 = mem.x1 = mem.x2 = 0; mem.set(0, 0);
   if (q[x] > 3) return x + 1;
@@ -251,9 +289,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_P
   Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
-  const uint8_t* q = a.seq + (size_t)rd * a.seq_stride;
   const int len = a.seq_len[rd];
-  Lists<IT> L; L.base = reinterpret_cast<Intv<IT>*>(a.scratch) + tid; L.stride = a.n_threads;
+  extern __shared__ uint32_t s_read[];
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
+  Lists<IT> L; L.base = reinterpret_cast<Intv<IT>*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
   Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = 0;
   // mem_collect_intv_new (baseline.cpp:387-422)
   for (int x = 0; x < len;) x = q[x] < 4 ? smem1a_new(f, len, q, x, 1, mem, L) : x + 1;
@@ -271,6 +310,128 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_P
   a.mem_num[rd] = mem.n;
 }
 
+
+// ---- the same work in three kernels (ACCG_SMEM_SPLIT=1) -----------------------------------------------------------------------
+// In the fused kernel a wavefront executes the union of its 64 reads' paths through three nested passes; counted on configs[4]
+// 29 % of the Occ lookups are the forward extensions of the first pass and 28 % the LAST-like third pass -- both plain "extend to
+// the right until it fails" loops whose total trip count per read is nearly the same for every read (the read length), and both
+// independent of everything else: the first pass restarts where the forward extension failed (bwt_smem1a_new returns that
+// position before it looks backwards), the third pass only appends behind the other two.  Run on their own, flattened to one
+// extension per iteration, they keep all 64 lanes busy:
+//   smem_fwd_kernel    forward halves of the whole first pass; the curr lists of all calls go to the scratch back to back, with a
+//                      segment table {x, first entry, entries} per read
+//   smem_back_kernel   backward halves over those lists, then the re-seeding pass (as in the fused kernel)
+//   smem_pass3_kernel  the third pass, appending behind what the second kernel stored
+// Same functions, same order of every push: the output is the fused kernel's bit for bit.
+// MEASURED (configs[4], round 2): the forward and third-pass kernels do run with 55 and 63 of 64 lanes and sit on the random-sector
+// ceiling of the memory system (3.3 + 2.5 ms at 12 wavefronts per CU -- more wavefronts make them SLOWER, 4.8 + 3.9 ms at 28 --
+// against 3.2 ms for the same number of dependent sector pairs in tools/ubench_random.hip), but the backward kernel alone takes
+// 9.1 ms: 14.9 ms in total against 13.9 ms for the one-kernel form, in which the issue-bound backward code of some wavefronts
+// overlaps the memory-bound forward code of others (taking the third pass out of the fused kernel saves it only 1 ms).  Kept
+// selectable and under test; the default is the fused kernel.
+template <typename IT>
+__global__ __launch_bounds__(64) void smem_fwd_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+  typedef Intv<IT> I;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_reads) return;
+  const uint32_t rd = read_base + tid;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
+  const int len = a.seq_len[rd];
+  extern __shared__ uint32_t s_read[];
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
+  Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  uint32_t* seg = a.seg + tid;
+  // one loop, one bwt_extend per iteration: a lane is either inside a forward extension (i < len, q[i] < 4) or between two
+  int n_tot = 0, n_seg = 0, x = 0, i = 0, seg0 = 0;
+  bool inside = false;
+  I ik; ik.x0 = ik.x1 = ik.x2 = 0; ik.set(0, 0);
+  while (x < len) {
+    if (!inside) {                       // mem_collect_intv_new's loop head (:394-400) + bwt_smem1a_new's prologue (:193-197)
+      if (q[x] > 3) { x++; continue; }
+      ik = set_intv1(f, q[x]); ik.set((uint32_t)(x + 1), 0);
+      i = x + 1; seg0 = n_tot; inside = true;
+    }
+    bool end = false;
+    if (i < len && q[i] < 4) {
+      const I nx = extend(f, ik, false, 3 - q[i]);
+      if (nx.x2 != ik.x2) { L.curr(n_tot++) = ik; end = nx.x2 < (IT)1; }
+      if (!end) { ik = nx; ik.set((uint32_t)(i + 1), 0); i++; }
+    } else { L.curr(n_tot++) = ik; end = true; }          // ambiguous base, or the end of the read (:211-216)
+    if (end) {
+      seg[(size_t)n_seg * a.n_threads] = (uint32_t)x | ((uint32_t)seg0 << 8) | ((uint32_t)(n_tot - seg0) << 18);
+      n_seg++;
+      x = (int)L.curr(n_tot - 1).lo();                    // ret (:217)
+      inside = false;
+    }
+  }
+  a.nseg[tid] = (uint32_t)n_seg;
+}
+
+template <typename IT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_PER_EU))) void smem_back_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_reads) return;
+  const uint32_t rd = read_base + tid;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
+  const int len = a.seq_len[rd];
+  extern __shared__ uint32_t s_read[];
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
+  Lists<IT> L; L.base = reinterpret_cast<Intv<IT>*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = 0;
+  const int n_seg = (int)a.nseg[tid];
+  for (int sgi = 0; sgi < n_seg; sgi++) {                 // first pass: the backward half of every call, on the list the forward kernel left
+    const uint32_t sg = a.seg[(size_t)sgi * a.n_threads + tid];
+    L.curr0 = (int)((sg >> 8) & 0x3FFu);
+    smem1a_back(f, len, q, (int)(sg & 0xFFu), 1, mem, L, (int)(sg >> 18));
+  }
+  L.curr0 = 0;
+  const int old_n = mem.n < (int)mem.cap ? mem.n : (int)mem.cap;   // entries beyond the slot are counted, not kept
+  for (int k = 0; k < old_n; k++) {
+    const SmemIntv p = mem.a[k];
+    const int start = (int)(p.info >> 32), end = (int)(int32_t)p.info;
+    if (end - start < 28 || p.x2 > 10) continue;
+    smem1a_new(f, len, q, (start + end) >> 1, (int)p.x2 + 1, mem, L);
+  }
+  a.mem_num[rd] = mem.n;
+}
+
+template <typename IT>
+__global__ __launch_bounds__(64) void smem_pass3_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+  typedef Intv<IT> I;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_reads) return;
+  const uint32_t rd = read_base + tid;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
+  const int len = a.seq_len[rd];
+  extern __shared__ uint32_t s_read[];
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
+  Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = a.mem_num[rd];
+  // bwt_seed_strategy1 (:306-327) from every restart point (:411-419), one bwt_extend per iteration
+  int x = 0, i = 0;
+  bool inside = false;
+  I ik; ik.x0 = ik.x1 = ik.x2 = 0; ik.set(0, 0);
+  while (x < len) {
+    if (!inside) {
+      if (q[x] > 3) { x++; continue; }
+      ik = set_intv1(f, q[x]); i = x + 1; inside = true;
+    }
+    if (i >= len) break;                                   // `return len`: nothing reported, the scan is over
+    if (q[i] >= 4) { x = i + 1; inside = false; continue; }
+    const I nx = extend(f, ik, false, 3 - q[i]);
+    if (nx.x2 < 20 && i - x >= MIN_SEED_LEN) {
+      I m = nx; m.set((uint32_t)(i + 1), (uint32_t)x);
+      if (m.x2 > 0) mem.push(m);
+      x = i + 1; inside = false;
+    } else { ik = nx; i++; }
+  }
+  a.mem_num[rd] = mem.n;
+}
 
 // ---- engine variant (32-bit intervals only) ----------------------------------------------------------------------------
 // In the kernel above the 64 reads of a wavefront share one program counter: a read that leaves a loop early idles until the
@@ -301,7 +462,7 @@ __global__ __launch_bounds__(64) void smem_engine(SmemArgs a, uint32_t read_base
   Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
-  Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads;
+  Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
   // the lane's current read, 4 bits per base, in LDS (row of 128 B per lane, rows 132 B apart to spread the banks): the
   // state machine looks at a base of the read in almost every transition
   __shared__ uint32_t s_read[64 * 33];
@@ -483,8 +644,27 @@ hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_
 
 hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
-  if (a.compact) hipLaunchKernelGGL(smem_kernel<uint32_t>, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, read_base, n_reads);
-  else hipLaunchKernelGGL(smem_kernel<uint64_t>, dim3((n_reads + 63) / 64), dim3(64), 0, s, a, read_base, n_reads);
+  const dim3 grid((n_reads + 63) / 64), block(64);
+  const size_t row = (size_t)64 * a.read_words * sizeof(uint32_t);
+  auto lds_for = [&](uint32_t waves_per_cu) {      // an LDS request that admits only this many wavefronts per CU (0: no limit)
+    return waves_per_cu ? std::max<size_t>(row, (160 * 1024 / waves_per_cu) & ~(size_t)255) : row;
+  };
+  if (a.seg) {         // three kernels (ACCG_SMEM_SPLIT=1)
+    const size_t lds_f = lds_for(a.waves_per_cu ? a.waves_per_cu : 12), lds_b = lds_for(a.waves_per_cu);
+    if (a.compact) {
+      hipLaunchKernelGGL(smem_fwd_kernel<uint32_t>, grid, block, lds_f, s, a, read_base, n_reads);
+      hipLaunchKernelGGL(smem_back_kernel<uint32_t>, grid, block, lds_b, s, a, read_base, n_reads);
+      hipLaunchKernelGGL(smem_pass3_kernel<uint32_t>, grid, block, lds_f, s, a, read_base, n_reads);
+    } else {
+      hipLaunchKernelGGL(smem_fwd_kernel<uint64_t>, grid, block, lds_f, s, a, read_base, n_reads);
+      hipLaunchKernelGGL(smem_back_kernel<uint64_t>, grid, block, lds_b, s, a, read_base, n_reads);
+      hipLaunchKernelGGL(smem_pass3_kernel<uint64_t>, grid, block, lds_f, s, a, read_base, n_reads);
+    }
+    return hipGetLastError();
+  }
+  const size_t lds = lds_for(a.waves_per_cu);
+  if (a.compact) hipLaunchKernelGGL(smem_kernel<uint32_t>, grid, block, lds, s, a, read_base, n_reads);
+  else hipLaunchKernelGGL(smem_kernel<uint64_t>, grid, block, lds, s, a, read_base, n_reads);
   return hipGetLastError();
 }
 

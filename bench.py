@@ -39,6 +39,7 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (fp
 N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32
 PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8,six-op column in gfx950 assembly>"
 SMEM_KERNEL_NAME = "smem_kernel<uint32_t>"
+SMEM_SECTOR_PEAK_G = 110.0      # G random 32-byte sectors/s, two dependent sectors per step (tools/ubench_random.hip)
 
 
 def traffic():
@@ -287,6 +288,11 @@ def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
                                "kernel": SMEM_KERNEL_NAME, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
                                "sectors_32B": {"achieved": ach / 2, "frac": ach / 2 / HBM_PEAK_GBS,
                                                "note": "bytes the re-laid-out index really serves: one 32-byte half-block per Occ lookup"},
+                               "random_sectors": {"achieved": lookups_per_read * n_reads / (k_ms * 1e-3) / 1e9, "peak": SMEM_SECTOR_PEAK_G,
+                                                  "unit": "G sectors/s", "frac": lookups_per_read * n_reads / (k_ms * 1e-3) / 1e9 / SMEM_SECTOR_PEAK_G,
+                                                  "note": "the bound that binds: dependent pairs of random 32-byte sector reads out of a 64 MB table, "
+                                                          "all 64 lanes active, measured by tools/ubench_random.hip on MI355X "
+                                                          "(profiles/r02_ubench_random.txt); lookups that share a sector with their twin count here too"},
                                "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
                                        "the path is bound by dependent lookups"},
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},
