@@ -369,6 +369,13 @@ __global__ __launch_bounds__(64) void smem_fwd_kernel(SmemArgs a, uint32_t read_
   a.nseg[tid] = (uint32_t)n_seg;
 }
 
+// Backward halves of the first pass over the lists the forward kernel left, then the re-seeding pass (as in the fused kernel).
+// Two other forms of this kernel were built and measured on configs[4], both bit-exact (DESIGN.md 4b has the numbers): one in
+// which the wavefront votes on which inner loop runs next (short "forwardenlarge" loops first, long "backenlarge" loops together),
+// and one flat loop with three extension states in which every round executes one bwt_extend for all lanes (25 of 64 lanes
+// instead of 10).  Both were slower than these nested loops (10.8 and 12.5 ms against 9.1 ms): with more lanes per round every
+// round waits for the slowest of more random loads -- the index sectors and, between two inner loops, the lane's list entries
+// in the HBM scratch -- and the launch is bound by that latency, not by the instruction count.
 template <typename IT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_PER_EU))) void smem_back_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;

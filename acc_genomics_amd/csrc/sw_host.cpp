@@ -157,7 +157,7 @@ extern "C" int accg_sw_batch_run(accg_sw_batch* b) {
 
 // Fill with the per-cell decision record, then the backtrace (calculateCigarOneBatch).  The record is
 // 256 B per step per group of two pairs (40 KB per pair at configs[2]); it lives in one scratch buffer of
-// at most ACCG_SW_BT_BYTES (default 16 GiB, env) that successive slices of the job list reuse.
+// at most ACCG_SW_BT_BYTES (default 16 GiB, env) whose two halves successive slices of the job list take in turn.
 extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   if (!b || max_el <= 0) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
@@ -180,34 +180,55 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   }
   uint64_t limit = 16ull << 30;
   if (const char* e = getenv("ACCG_SW_BT_BYTES")) limit = strtoull(e, nullptr, 10);
-  // size the scratch for the largest slice any launch will use
-  uint64_t need = 0;
+  // The scratch is two halves: while the backtrace of one slice walks its record (one thread per pair, dependent loads: latency
+  // bound) on an aux stream, the fill of the next slice (packed-VALU bound) writes the other half on the main stream.  A launch
+  // is cut into at least SW_BT_MIN_SLICES slices so that there is something to overlap.
+  constexpr uint64_t SW_BT_MIN_SLICES = 6;
+  auto slice_items = [&](const SwLaunch& l, uint64_t per) {
+    const uint64_t by_mem = std::max<uint64_t>(1, (limit / 2) / per);
+    const uint64_t by_cut = std::max<uint64_t>(4096, (l.n_work + SW_BT_MIN_SLICES - 1) / SW_BT_MIN_SLICES);
+    return std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, std::min(by_mem, by_cut)));
+  };
+  uint64_t half = 0;
   for (const SwLaunch& l : b->launches) {
     const uint64_t per = sw_bt_item_uint4(l.sweep_cap, l.lpp) * sizeof(uint4);
-    const uint64_t items = std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, limit / per));
-    need = std::max(need, items * per);
+    half = std::max(half, slice_items(l, per) * per);
   }
-  if (need > b->bt_bytes) {
+  half = (half + 255) & ~(uint64_t)255;
+  if (2 * half > b->bt_bytes) {
     ACCG_HIP(hipStreamSynchronize(s));
     if (b->d_bt) b->ctx->pool.put(b->d_bt);
     b->d_bt = nullptr; b->bt_bytes = 0;
-    { int st_ = dev_alloc(b->ctx, &b->d_bt, need); if (st_ != ACCG_OK) return st_; }
-    b->bt_bytes = need;
+    { int st_ = dev_alloc(b->ctx, &b->d_bt, 2 * half); if (st_ != ACCG_OK) return st_; }
+    b->bt_bytes = 2 * half;
   }
   SwArgs a = b->args;
-  a.bt = b->d_bt; a.cig_n = b->d_cig_n; a.cig_off = b->d_cig_off; a.cig_el = b->d_cig_el; a.max_el = max_el;
+  a.cig_n = b->d_cig_n; a.cig_off = b->d_cig_off; a.cig_el = b->d_cig_el; a.max_el = max_el;
   a.cig_packed = b->d_cig_packed; a.cig_start = b->d_cig_start; a.cig_total = b->d_cig_total;
   ACCG_HIP(hipMemsetAsync(b->d_cig_total, 0, sizeof(unsigned long long), s));
+  accg_ctx* c = b->ctx;
+  hipStream_t st = c->aux[0];
+  ACCG_HIP(ctx_fork(c));                                   // the trace stream starts behind everything queued so far (the memset)
+  bool used[2] = {false, false};
+  uint32_t k = 0;
   for (const SwLaunch& l : b->launches) {
     a.bt_item_stride = sw_bt_item_uint4(l.sweep_cap, l.lpp);
     const uint64_t per = a.bt_item_stride * sizeof(uint4);
-    const uint32_t slice = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, b->bt_bytes / per));
-    for (uint32_t off = 0; off < l.n_work; off += slice) {
+    const uint32_t slice = (uint32_t)slice_items(l, per);
+    for (uint32_t off = 0; off < l.n_work; off += slice, k++) {
       const uint32_t n = std::min(slice, l.n_work - off), w0 = l.work0 + off;
+      const int h = (int)(k & 1);
+      a.bt = reinterpret_cast<uint4*>(reinterpret_cast<char*>(b->d_bt) + (size_t)h * (b->bt_bytes / 2));
+      if (used[h]) ACCG_HIP(hipStreamWaitEvent(s, c->ev_join[h], 0));      // the walk over this half's previous record is through
       ACCG_HIP(sw_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, true, a, w0, n, w0, l.sweep_cap, s));
-      ACCG_HIP(sw_trace_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, a, w0, n, w0, l.sweep_cap, s));
+      ACCG_HIP(hipEventRecord(c->ev_fork, s));
+      ACCG_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
+      ACCG_HIP(sw_trace_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, a, w0, n, w0, l.sweep_cap, st));
+      ACCG_HIP(hipEventRecord(c->ev_join[h], st));
+      used[h] = true;
     }
   }
+  for (int h = 0; h < 2; h++) if (used[h]) ACCG_HIP(hipStreamWaitEvent(s, c->ev_join[h], 0));
   return ACCG_OK;
 }
 
