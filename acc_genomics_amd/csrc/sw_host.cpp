@@ -233,31 +233,71 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
 }
 
 // The CIGARs leave the device packed back to back (a few elements per pair); the fixed-slot layout of the reference's
-// Cigar arrays is rebuilt on the host.
+// Cigar arrays is rebuilt on the host.  One pinned staging block takes [total][starts][n_el][offsets][elements]: two copies
+// (the 8-byte total first, to size the block), and the view form hands out pointers into it instead of copying again.
+extern "C" int accg_sw_batch_cigars_packed_view(accg_sw_batch* b, const int32_t** n_el, const int32_t** offsets, const uint64_t** starts,
+                                                const int32_t** elements, uint64_t* total) {
+  if (!b || !b->d_cig_n) return ACCG_ERR_BAD_ARG;
+  accg_ctx* c = b->ctx;
+  ACCG_HIP(hipSetDevice(c->device));
+  const size_t n1 = std::max<size_t>((size_t)b->n, 1);
+  const size_t meta = ((1 + n1) * sizeof(unsigned long long) + 2 * n1 * sizeof(int32_t) + 15) & ~(size_t)15;
+  void* stage = nullptr;
+  ACCG_HIP(ctx_stage(c, meta, &stage));
+  ACCG_HIP(hipMemcpyAsync(stage, b->d_cig_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  ACCG_HIP(hipStreamSynchronize(c->stream));
+  const unsigned long long tot = *(const unsigned long long*)stage;
+  const size_t el_bytes = (size_t)tot * 2 * sizeof(int32_t);
+  ACCG_HIP(ctx_stage(c, meta + el_bytes, &stage));        // may move the block: everything is copied after this
+  ACCG_HIP(hipMemcpyAsync(stage, b->d_cig_total, (1 + n1) * sizeof(unsigned long long) + 2 * n1 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (el_bytes) ACCG_HIP(hipMemcpyAsync((char*)stage + meta, b->d_cig_packed, el_bytes, hipMemcpyDeviceToHost, c->stream));
+  ACCG_HIP(hipStreamSynchronize(c->stream));
+  const unsigned long long* m64 = (const unsigned long long*)stage;
+  const int32_t* m32 = (const int32_t*)(m64 + 1 + n1);
+  if (total) *total = tot;
+  if (starts) *starts = (const uint64_t*)(m64 + 1);
+  if (n_el) *n_el = m32;
+  if (offsets) *offsets = m32 + n1;
+  if (elements) *elements = (const int32_t*)((const char*)stage + meta);
+  return ACCG_OK;
+}
+
+namespace {
+void par_copy(void* dst, const void* src, size_t bytes) {          // memcpy over the host threads the process may use
+  const int T = accg::host_threads();
+  if (bytes < (8u << 20) || T < 2) { memcpy(dst, src, bytes); return; }
+#pragma omp parallel for schedule(static) num_threads(T)
+  for (int t = 0; t < T; t++) {
+    const size_t a = bytes * t / T, e = bytes * (t + 1) / T;
+    memcpy((char*)dst + a, (const char*)src + a, e - a);
+  }
+}
+}  // namespace
+
 extern "C" int accg_sw_batch_cigars_packed(accg_sw_batch* b, int32_t* n_el, int32_t* offsets, uint64_t* starts, int32_t* elements,
                                            uint64_t capacity, uint64_t* total) {
   if (!b || !b->d_cig_n) return ACCG_ERR_BAD_ARG;
-  ACCG_HIP(hipSetDevice(b->ctx->device));
-  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   const size_t n = (size_t)b->n;
-  const size_t n1 = std::max<size_t>(n, 1);
-  const size_t meta = (1 + n1) * sizeof(unsigned long long) + 2 * n1 * sizeof(int32_t);
-  void* stage = nullptr;
-  ACCG_HIP(ctx_stage(b->ctx, meta, &stage));
-  ACCG_HIP(hipMemcpyAsync(stage, b->d_cig_total, meta, hipMemcpyDeviceToHost, b->ctx->stream));
-  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-  const unsigned long long* m64 = (const unsigned long long*)stage;
-  const int32_t* m32 = (const int32_t*)(m64 + 1 + n1);
-  const unsigned long long tot = m64[0];
+  if (!elements && !n_el && !offsets && !starts) {         // size query: the total alone
+    ACCG_HIP(hipSetDevice(b->ctx->device));
+    unsigned long long tot = 0;
+    ACCG_HIP(hipMemcpyAsync(&tot, b->d_cig_total, sizeof tot, hipMemcpyDeviceToHost, b->ctx->stream));
+    ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (total) *total = tot;
+    return ACCG_OK;
+  }
+  const int32_t *v_n, *v_off, *v_el; const uint64_t* v_st; uint64_t tot = 0;
+  int st = accg_sw_batch_cigars_packed_view(b, &v_n, &v_off, &v_st, &v_el, &tot);
+  if (st != ACCG_OK) return st;
   if (total) *total = tot;
   if (n) {
-    if (n_el) memcpy(n_el, m32, n * sizeof(int32_t));
-    if (offsets) memcpy(offsets, m32 + n1, n * sizeof(int32_t));
-    if (starts) memcpy(starts, m64 + 1, n * sizeof(uint64_t));
+    if (n_el) par_copy(n_el, v_n, n * sizeof(int32_t));
+    if (offsets) par_copy(offsets, v_off, n * sizeof(int32_t));
+    if (starts) par_copy(starts, v_st, n * sizeof(uint64_t));
   }
   if (elements) {
-    if (capacity < tot) return ACCG_ERR_BAD_ARG;      // *total says how much is needed
-    if (tot) ACCG_HIP(hipMemcpy(elements, b->d_cig_packed, tot * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (capacity < tot) return ACCG_ERR_BAD_ARG;           // *total says how much is needed
+    par_copy(elements, v_el, (size_t)tot * 2 * sizeof(int32_t));
   }
   return ACCG_OK;
 }
@@ -266,21 +306,15 @@ extern "C" int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* of
   if (!b || !b->d_cig_n) return ACCG_ERR_BAD_ARG;
   const size_t n = (size_t)b->n;
   if (!elements) return accg_sw_batch_cigars_packed(b, n_el, offsets, nullptr, nullptr, 0, nullptr);
-  std::vector<int32_t> cnt(n);
-  std::vector<uint64_t> starts(n);
-  uint64_t tot = 0;
-  int st = accg_sw_batch_cigars_packed(b, cnt.data(), offsets, starts.data(), nullptr, 0, &tot);
-  if (st != ACCG_OK) return st;
-  void* stage = nullptr;                                   // the context's pinned staging
-  ACCG_HIP(ctx_stage(b->ctx, tot * 2 * sizeof(int32_t) + 16, &stage));
-  const int32_t* packed = (const int32_t*)stage;
-  st = accg_sw_batch_cigars_packed(b, nullptr, nullptr, nullptr, (int32_t*)stage, tot, nullptr);
+  const int32_t *cnt, *v_off, *packed; const uint64_t* starts; uint64_t tot = 0;
+  int st = accg_sw_batch_cigars_packed_view(b, &cnt, &v_off, &starts, &packed, &tot);
   if (st != ACCG_OK) return st;
   const size_t slot = (size_t)b->max_el * 2;
 #pragma omp parallel for schedule(static) num_threads(accg::host_threads())
   for (size_t k = 0; k < n; k++)
     if (cnt[k] > 0) memcpy(elements + k * slot, packed + starts[k] * 2, (size_t)cnt[k] * 2 * sizeof(int32_t));
-  if (n_el) memcpy(n_el, cnt.data(), n * sizeof(int32_t));
+  if (n && n_el) memcpy(n_el, cnt, n * sizeof(int32_t));
+  if (n && offsets) memcpy(offsets, v_off, n * sizeof(int32_t));
   return ACCG_OK;
 }
 

@@ -78,6 +78,7 @@ def load():
     L.accg_sw_batch_run_cigar.argtypes = [vp, C.c_int]
     L.accg_sw_batch_cigars.argtypes = [vp, vp, vp, vp]
     L.accg_sw_batch_cigars_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp]
+    L.accg_sw_batch_cigars_packed_view.argtypes = [vp, vp, vp, vp, vp, vp]
     L.accg_smem_index_create.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(vp)]
     L.accg_smem_index_destroy.argtypes = [vp]
     L.accg_smem_index_words.restype = C.c_uint64
@@ -263,14 +264,18 @@ class SwBatch:
         _check(self.L.accg_sw_batch_cigars(self.h, n_el.ctypes.data, off.ctypes.data, el.ctypes.data))
         return n_el, off, el
 
-    def cigars_packed(self):
-        """-> (n_el int32[n], alignment_offset int32[n], starts uint64[n], elements int32[total, 2]): CIGARs back to back."""
-        n_el, off = np.zeros(self.n, np.int32), np.zeros(self.n, np.int32)
-        starts = np.zeros(self.n, np.uint64)
-        total = C.c_uint64()
-        _check(self.L.accg_sw_batch_cigars_packed(self.h, n_el.ctypes.data, off.ctypes.data, starts.ctypes.data, None, 0, C.byref(total)))
-        el = np.zeros((total.value, 2), np.int32)
-        _check(self.L.accg_sw_batch_cigars_packed(self.h, None, None, None, el.ctypes.data, total.value, None))
+    def cigars_packed(self, copy=True):
+        """-> (n_el int32[n], alignment_offset int32[n], starts uint64[n], elements int32[total, 2]): CIGARs back to back.
+        copy=False: views of the context's pinned staging block (accg_sw_batch_cigars_packed_view), valid until the next results call."""
+        pn, po, pe, ps, total = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_uint64)(), C.c_uint64()
+        _check(self.L.accg_sw_batch_cigars_packed_view(self.h, C.byref(pn), C.byref(po), C.byref(ps), C.byref(pe), C.byref(total)))
+        if self.n == 0:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint64), np.zeros((0, 2), np.int32)
+        n_el, off = np.ctypeslib.as_array(pn, (self.n,)), np.ctypeslib.as_array(po, (self.n,))
+        starts = np.ctypeslib.as_array(ps, (self.n,))
+        el = np.ctypeslib.as_array(pe, (total.value, 2)) if total.value else np.zeros((0, 2), np.int32)
+        if copy:
+            return n_el.copy(), off.copy(), starts.copy(), el.copy()
         return n_el, off, starts, el
 
     def close(self):

@@ -191,11 +191,11 @@ def bench_sw(ctx, comm, steps, warmup, with_cpu):
     if rank == 0:
         k_ms = b.time(warmup=1, iters=max(3, steps))
         # full SWPairwiseAlignment (fill + decision record + backtrace -> CIGAR), what the reference's CPU path is timed on
-        b.run_cigar(48); b.cigars_packed()
+        b.run_cigar(48); b.cigars_packed(copy=False)
         tc0 = time.perf_counter()
         for _ in range(3):
             b.run_cigar(48)
-            b.cigars_packed()                             # every pass brings its CIGARs back to the host (packed form)
+            b.cigars_packed(copy=False)                   # every pass brings its CIGARs back into (pinned) host memory, packed form
         cigar_ms = (time.perf_counter() - tc0) / 3 * 1e3
         check = None
         if with_cpu:                                    # the measured batch against the oracle on a sample (checker only, untimed)

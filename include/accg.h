@@ -143,6 +143,10 @@ int accg_sw_batch_cigars(accg_sw_batch* b, int32_t* n_el, int32_t* alignment_off
  * *total = elements in all; elements (capacity in elements) may be NULL to query it.  Any pointer may be NULL. */
 int accg_sw_batch_cigars_packed(accg_sw_batch* b, int32_t* n_el, int32_t* alignment_offsets, uint64_t* starts, int32_t* elements,
                                 uint64_t capacity, uint64_t* total);
+/* Zero-copy form of the same: pointers into the context's pinned host staging block, filled by two device-to-host copies and
+ * valid until the next call on this context that returns results.  Any pointer may be NULL. */
+int accg_sw_batch_cigars_packed_view(accg_sw_batch* b, const int32_t** n_el, const int32_t** alignment_offsets, const uint64_t** starts,
+                                     const int32_t** elements, uint64_t* total);
 void accg_sw_batch_destroy(accg_sw_batch* b);
 
 /* ---- SMEM seeding (BWA-MEM, configs[4]) -----------------------------------------------------------------

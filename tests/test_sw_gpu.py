@@ -3,6 +3,8 @@ the reference CPU path (golden vectors from the reference build; oracle for ever
 import glob
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -263,6 +265,13 @@ def test_packed_cigars_agree_with_slots(ctx):
         pn, poff, starts, pel = b.cigars_packed()
         b.run_cigar(128)                                   # a second run starts from an empty packed buffer again
         pn2, _, starts2, pel2 = b.cigars_packed()
+        vn, voff, vstarts, vel = b.cigars_packed(copy=False)        # zero-copy views of the pinned staging block
+        assert np.array_equal(vn, pn2) and np.array_equal(voff, poff) and np.array_equal(vstarts, starts2) and np.array_equal(vel, pel2)
+        tot = C.c_uint64()
+        assert b.L.accg_sw_batch_cigars_packed(b.h, None, None, None, None, 0, C.byref(tot)) == 0 and tot.value == len(pel2)
+        small = np.zeros((max(len(pel2) - 1, 1), 2), np.int32)      # a too small element buffer is refused, the total still reported
+        assert b.L.accg_sw_batch_cigars_packed(b.h, None, None, None, small.ctypes.data, len(small), C.byref(tot)) == -3  # ACCG_ERR_BAD_ARG
+        assert tot.value == len(pel2)
     assert np.array_equal(pn, n_el) and np.array_equal(poff, off) and np.array_equal(pn2, n_el)
     cnt = np.maximum(pn, 0)
     assert len(pel) == int(cnt.sum()) == len(pel2)

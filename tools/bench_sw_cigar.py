@@ -19,3 +19,7 @@ with A.Context(0) as ctx:
         t0 = time.perf_counter(); n_el, off, el = b.cigars(); print("D2H cigars %.2f ms" % ((time.perf_counter() - t0) * 1e3))
         print("mean elements", n_el.mean(), "max", n_el.max())
         t0 = time.perf_counter(); pn, poff, starts, pel = b.cigars_packed(); print("D2H packed cigars %.2f ms (%d elements)" % ((time.perf_counter() - t0) * 1e3, len(pel)))
+        for it in range(3):
+            t0 = time.perf_counter(); pn, poff, starts, pel = b.cigars_packed(copy=False); print("D2H packed cigars, pinned view %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+        for it in range(3):
+            t0 = time.perf_counter(); b.run_cigar(48); b.cigars_packed(copy=False); print("run_cigar + view %.2f ms" % ((time.perf_counter() - t0) * 1e3))
