@@ -53,11 +53,16 @@ template <> struct Val<true> {
   static __device__ __forceinline__ int bits(T a) { return __builtin_bit_cast(int, a); }
   static __device__ __forceinline__ T from_bits(int b) { return __builtin_bit_cast(T, b); }
   static __device__ __forceinline__ int get(T a, int half) { return half ? (int)a.y : (int)a.x; }
-  // (a < b) per half as 0/1 at bits 0 and 16: sign of the saturating difference
-  static __device__ __forceinline__ unsigned lt(T a, T b) {
-    u2 d = __builtin_bit_cast(u2, __builtin_elementwise_sub_sat(a, b));
-    return __builtin_bit_cast(unsigned, (u2)(d >> 15));
+  // plane with (a < b) of both halves shifted in: the sign bits of the saturating difference go to bits 15 and 31, what was
+  // there moves down by one (a 32-bit shift is enough: at most 16 bits are ever collected, so nothing crosses into the other
+  // half).  v_pk_sub_i16 clamp + v_lshrrev_b32 + v_and_or_b32: one half-rate packed operation and two full-rate ones per
+  // plane and cell pair; the earlier v_pk_lshrrev_b16 + shift + or form had two packed ones and 2.1 others.
+  static __device__ __forceinline__ unsigned push_lt(unsigned plane, T a, T b) {
+    const unsigned d = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(a, b));
+    return (plane >> 1) | (d & 0x80008000u);
   }
+  // where the bit of local row k ends up after all K rows of a step went in
+  static __device__ __forceinline__ int plane_bit(int K, int k, int half) { return 16 - K + k + 16 * half; }
   enum { NEG = NEG16 };
 };
 template <> struct Val<false> {
@@ -70,7 +75,8 @@ template <> struct Val<false> {
   static __device__ __forceinline__ int bits(T a) { return a; }
   static __device__ __forceinline__ T from_bits(int b) { return b; }
   static __device__ __forceinline__ int get(T a, int) { return a; }
-  static __device__ __forceinline__ unsigned lt(T a, T b) { return (unsigned)(a - b) >> 31; }   // |values| < 2^30 + 2^20
+  static __device__ __forceinline__ unsigned push_lt(unsigned plane, T a, T b) { return (plane << 1) | ((unsigned)(a - b) >> 31); }   // |values| < 2^30 + 2^20
+  static __device__ __forceinline__ int plane_bit(int K, int k, int) { return K - 1 - k; }
   enum { NEG = NEG32 };
 };
 
@@ -110,7 +116,7 @@ __device__ __forceinline__ unsigned long long group_max_u64(unsigned long long v
 }
 
 // Backtrace record (BT = true).  Every (step t, lane) stores one uint4 = four bit planes; plane bit
-// (K-1-k) + 16*half belongs to the cell (lane position of local row k, sweep index t - lane):
+// Val<P16>::plane_bit(K, k, half) belongs to the cell (lane position of local row k, sweep index t - lane):
 //   x: lane-direction gap OPENED here  (open > extension, strictly: FalconSW_AVX.cpp:1774 / :1786)
 //   y: sweep-direction gap OPENED here
 //   z: cell is NOT diagonal            (diag >= down && diag >= right fails, :1798)
@@ -223,10 +229,10 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
         const T m = VT::mx(G[k], f);
         const T hn = VT::mx(dg, m);
         if (BT) {
-          pf = (pf << 1) | VT::lt(fe, fo);
-          pg = (pg << 1) | VT::lt(ge, go);
-          pn = (pn << 1) | VT::lt(dg, m);
-          pd = (pd << 1) | (LANE_IS_ALT ? VT::lt(f, G[k]) : VT::lt(G[k], f));   // right < down
+          pf = VT::push_lt(pf, fe, fo);
+          pg = VT::push_lt(pg, ge, go);
+          pn = VT::push_lt(pn, dg, m);
+          pd = LANE_IS_ALT ? VT::push_lt(pd, f, G[k]) : VT::push_lt(pd, G[k], f);   // right < down
         }
         hdiag = hold; hup = hn; Hp[k] = hn;
         fo = VT::adds(hn, opn_s); Ho[k] = fo;
@@ -337,7 +343,7 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   auto entry = [&](int i, int j, int& shift) -> const uint4* {
     const int sidx = LANE_IS_ALT ? i : j, pos = LANE_IS_ALT ? j : i;
     const int flat = pos - 1 + pad, l = flat / K, k = flat - l * K;
-    shift = K - 1 - k + 16 * half;
+    shift = p16 ? Val<true>::plane_bit(K, k, half) : Val<false>::plane_bit(K, k, half);
     return bt + (uint64_t)(sidx + l) * LPP + l;
   };
   do {
