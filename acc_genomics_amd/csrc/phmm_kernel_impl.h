@@ -362,6 +362,15 @@ template <int K> struct AsmCol<double, K> {
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
 // would cap the fp64 rescue kernel's LDS).
+#ifdef PHMM_TIMING
+static __device__ unsigned long long g_phmm_t[8];
+static __global__ void phmm_timing_print() {
+  const double n = (double)g_phmm_t[0];
+  printf("phmm timing per job (s_memtime ticks): prologue %.0f = stream %.0f + row loads %.0f + dist table %.0f + rest %.0f; sweep %.0f\n", g_phmm_t[1] / n,
+         g_phmm_t[3] / n, g_phmm_t[4] / n, g_phmm_t[5] / n, g_phmm_t[6] / n, g_phmm_t[2] / n);
+  for (int i = 0; i < 8; i++) g_phmm_t[i] = 0;
+}
+#endif
 template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false, bool STRIPED = false>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -378,6 +387,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   T* carry_x = carry_a + (a.stream_cap + 2 * LPP + 24);
 
   const int lane = threadIdx.x;
+#ifdef PHMM_TIMING
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int NG = 64 / LPP;              // reads per wavefront
   const int g = lane / LPP, l = lane % LPP;
   // (field-wise loads: indexing a by-value copy of the struct with g would put it in scratch)
@@ -421,7 +433,15 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       y0s[n_haps] = a.tab.init / (T)(int)hr.len;     // baseline_impl.cpp:63
       hcol[n_haps] = col;
     }
-    for (int i = lane; i < (int)hr.len; i += 64) stream[LPP - 1 + pos + 1 + i] = (uint8_t)char_index(a.hblob[hr.off + i]);
+    // the bases, eight byte loads per lane in flight before the first one is used (512 bases per round trip: one lane-strided
+    // byte at a time, a 300-base haplotype cost five memory latencies in a row -- 19 of them per configs[1] job, 15 us of its 22 us prologue)
+    for (int i0 = 0; i0 < (int)hr.len; i0 += 512) {
+      uint8_t hb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + lane; hb[u] = i < (int)hr.len ? a.hblob[hr.off + i] : (uint8_t)0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + lane; if (i < (int)hr.len) stream[LPP - 1 + pos + 1 + i] = (uint8_t)char_index(hb[u]); }
+    }
     pos += (int)hr.len + 1;
     n_haps++;
   }
@@ -432,6 +452,10 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   if (lane == 0) { bpos[n_haps] = pos; bpos[n_haps + 1] = 0x7FFFFFFF; y0s[n_haps] = T(0); hcol[n_haps] = 0; }
   for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = 0;   // terminal bubble + drain + prefetch slack
   const int t_end = __builtin_amdgcn_readfirstlane(pos + LPP);         // the last lane passes the terminal bubble at pos+LPP-1
+#ifdef PHMM_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long tmA = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- per-row constants (registers) and the dist table (LDS) ---------------------------------
   // A read of more than LPP * K - 1 bases (STRIPED, 64 lanes x 16 rows) is swept in stripes of LPP * K rows, top to bottom
@@ -478,6 +502,10 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       tdX[k] = a.tab.phd3[vq[k]];                        // baseline_impl.cpp:83
     }
   }
+#ifdef PHMM_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long tmB = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
   for (int q = 0; q < QT; q++) {
     T dM[VN], dX[VN];
@@ -516,6 +544,10 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       }
     }
   }
+#ifdef PHMM_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long tmC = __builtin_amdgcn_s_memtime();
+#endif
   {
     const int r = roff + (l + 1) * K - pad; // row 0 of the lane to the right (of the next stripe, for the last lane of a stripe that has one)
     if ((l < LPP - 1 || !last_stripe) && r >= roff) { s.nMM = tMM[K]; s.nGM = tGM[K]; s.nMX = tMX[K]; s.nXX = tXX[K]; }
@@ -584,6 +616,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     // the steps past t_end run over the stream's padding after the terminal bubble and write nothing.
     constexpr int U = 8;
     const int t_stop = (t_end + U - 1) / U * U;
+#ifdef PHMM_TIMING
+    const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
     while (t < t_stop) {
       const unsigned hs_t = hs_a + (unsigned)t;
 #pragma unroll
@@ -625,6 +660,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       }
       t += U;
     }
+#ifdef PHMM_TIMING
+    if (lane == 0) { const unsigned long long tm2 = __builtin_amdgcn_s_memtime(); atomicAdd(&g_phmm_t[0], 1ull); atomicAdd(&g_phmm_t[1], tm1 - tm0); atomicAdd(&g_phmm_t[2], tm2 - tm1); atomicAdd(&g_phmm_t[3], tmA - tm0); atomicAdd(&g_phmm_t[4], tmB - tmA); atomicAdd(&g_phmm_t[5], tmC - tmB); atomicAdd(&g_phmm_t[6], tm1 - tmC); }
+#endif
     return __any(tiny);
   }
   T dn[K];                    // dist of step t (loaded one step ahead)
