@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised SMEM parity run (GPU vs the oracle): random genomes (uniform, low-complexity, repeat-rich), read lengths
-1..255, substitutions, ambiguous bases, both index layouts and the engine variant.  usage: tools/fuzz_smem.py [rounds] [seed]"""
+1..255, substitutions, ambiguous bases, both index layouts, the three-kernel form and the engine variant.  usage: tools/fuzz_smem.py [rounds] [seed]"""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,8 +35,9 @@ for it in range(rounds):
     n = len(reads)
     want = np.zeros((n, max_out, 4), np.uint64); wnum = np.zeros(n, np.int32)
     O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, n, max_out, want.ctypes.data, wnum.ctypes.data, 16)
-    for env in ({}, {"ACCG_SMEM_COMPACT": "0"}, {"ACCG_SMEM_ENGINE": "1", "ACCG_SMEM_ENGINE_WAVES": "5"}):
-        for k in ("ACCG_SMEM_COMPACT", "ACCG_SMEM_ENGINE", "ACCG_SMEM_ENGINE_WAVES"): os.environ.pop(k, None)
+    for env in ({}, {"ACCG_SMEM_COMPACT": "0"}, {"ACCG_SMEM_ENGINE": "1", "ACCG_SMEM_ENGINE_WAVES": "5"}, {"ACCG_SMEM_SPLIT": "1"},
+                {"ACCG_SMEM_SPLIT": "1", "ACCG_SMEM_COMPACT": "0"}):
+        for k in ("ACCG_SMEM_COMPACT", "ACCG_SMEM_ENGINE", "ACCG_SMEM_ENGINE_WAVES", "ACCG_SMEM_SPLIT"): os.environ.pop(k, None)
         os.environ.update(env)
         with A.Context(0) as ctx, A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, max_out) as b:
             b.run(); got, gnum = b.results()
