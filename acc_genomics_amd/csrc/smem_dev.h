@@ -11,9 +11,18 @@ struct alignas(16) SmemIntv { uint64_t x0, x1, x2, info; };   // bwtintv_t: {x[0
 constexpr int SMEM_CURR_CAP = 512;
 constexpr int SMEM_SCRATCH_ENTRIES = SMEM_CURR_CAP + 256;
 
+// Prefix table: what SMEM_KTAB_L forward bwt_extend calls from a single base arrive at, for every string of that many bases
+// (4^10 x 16 B = 16.8 MB for the last level, 22.4 MB in all).  A forward extension that starts on SMEM_KTAB_L clean bases takes
+// its first intervals from here -- independent loads, one memory latency -- instead of 2 (SMEM_KTAB_L - 1) dependent lookups.
+constexpr int SMEM_KTAB_L = 10;
+__host__ __device__ constexpr uint32_t smem_ktab_off(int L) { return (uint32_t)(((1ull << (2 * L)) - 4) / 3); }   // entries in front of level L
+constexpr uint32_t SMEM_KTAB_ENTRIES = (uint32_t)(((1ull << (2 * (SMEM_KTAB_L + 1))) - 4) / 3);
+
 struct SmemArgs {
   const uint32_t* bwt;          // BWA block layout, 64 B per 128 symbols (smem/host/baseline.cpp:26-37)
   uint64_t primary, L2[5];
+  const uint4* ktab;            // compact index only, may be null: bi-intervals {x0, x1, x2, 0} of every string of 1 .. SMEM_KTAB_L bases
+                                //   (level L at smem_ktab_off(L), entry = the bases read as a base-4 number, first base most significant)
   uint32_t compact;             // 1: re-laid-out index, 32 B per 64 symbols = 4 x u32 cumulative counts + 4 x 16 symbols (smem_host.cpp)
   const uint8_t* seq;           // n_reads x seq_stride codes (0-3, >= 4 ambiguous)
   const uint8_t* seq_len;
@@ -31,6 +40,8 @@ struct SmemArgs {
 };
 
 hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s);
+// fills ktab (SMEM_KTAB_ENTRIES x uint4) level by level with the kernel's own bwt_extend; a.ktab is ignored
+hipError_t smem_build_ktab(const SmemArgs& a, uint4* ktab, hipStream_t s);
 // persistent wavefronts that take reads from a queue; compact (32-bit) index only; scratch for n_waves x 64 threads
 hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s);
 

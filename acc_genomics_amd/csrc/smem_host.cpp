@@ -13,9 +13,10 @@ using namespace accg;
 struct accg_smem_index {
   accg_ctx* ctx = nullptr;
   uint32_t* d_bwt = nullptr;
+  uint4* d_ktab = nullptr;        // prefix table (smem_dev.h), compact layout only
   uint64_t words = 0, primary = 0, L2[5] = {0};
   bool compact = false;
-  ~accg_smem_index() { if (d_bwt) hipFree(d_bwt); }
+  ~accg_smem_index() { if (d_bwt) hipFree(d_bwt); if (d_ktab) hipFree(d_ktab); }
 };
 
 struct accg_smem_batch {
@@ -84,6 +85,15 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
       }
     }
     ACCG_HIP(hipMemcpy(x->d_bwt, cb.data(), bwt_words * 4, hipMemcpyHostToDevice));
+    const char* ek = getenv("ACCG_SMEM_KTAB");           // A/B knob: 0 = no prefix table
+    if (!(ek && ek[0] == '0')) {
+      ACCG_HIP(hipMalloc((void**)&x->d_ktab, (size_t)SMEM_KTAB_ENTRIES * sizeof(uint4)));
+      SmemArgs a{};
+      a.bwt = x->d_bwt; a.primary = x->primary; a.compact = 1u;
+      for (int c = 0; c < 5; c++) a.L2[c] = x->L2[c];
+      ACCG_HIP(smem_build_ktab(a, x->d_ktab, ctx->stream));
+      ACCG_HIP(hipStreamSynchronize(ctx->stream));
+    }
   } else {
     ACCG_HIP(hipMemcpy(x->d_bwt, bwt, bwt_words * 4, hipMemcpyHostToDevice));
   }
@@ -149,14 +159,14 @@ extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
   accg_smem_index* x = b->idx;
   ACCG_HIP(hipSetDevice(x->ctx->device));
   SmemArgs a;
-  a.bwt = x->d_bwt; a.primary = x->primary; a.compact = x->compact ? 1u : 0u;
+  a.bwt = x->d_bwt; a.primary = x->primary; a.compact = x->compact ? 1u : 0u; a.ktab = x->d_ktab;
   for (int c = 0; c < 5; c++) a.L2[c] = x->L2[c];
   a.seq = b->d_seq; a.seq_len = b->d_len; a.seq_stride = b->stride; a.n_reads = b->n;
   a.out = b->d_out; a.mem_num = b->d_num; a.max_out = b->max_out; a.scratch = b->d_scratch; a.n_threads = b->slice;
   a.seg = b->d_seg; a.nseg = b->d_nseg;
   a.read_words = ((b->longest + 7) / 8) | 1u;
-  // wavefronts per CU (by an LDS request): the fused kernel fits 32 at its 63 VGPRs and measures best at 24 (13.5 against 13.8 ms on
-  // configs[4]); the split form picks per kernel (smem_launch).  ACCG_SMEM_WPC overrides, 0 = no limit.
+  // wavefronts per CU (by an LDS request): at most 24 for the fused kernel (measured best when it needed 63 VGPRs; with the prefix
+  // table it needs 86 and 20 fit anyway); the split form picks per kernel (smem_launch).  ACCG_SMEM_WPC overrides, 0 = no limit.
   { const char* e = getenv("ACCG_SMEM_WPC"); a.waves_per_cu = e ? (uint32_t)atoi(e) : (b->d_seg ? 0u : 24u); }
   if (b->engine_waves) {
     a.queue = b->d_queue;

@@ -44,6 +44,7 @@ template <typename IT>
 struct Ctx {
   const uint32_t* bwt;
   IT primary, L2[5];
+  const uint4* ktab;        // prefix table (smem_dev.h), null: none
 };
 
 // number of symbols equal to c among the first `upto + 1` symbols (0-based, MSB first) of NW words of 16 symbols
@@ -178,21 +179,59 @@ __device__ __forceinline__ ReadLds stage_read(uint32_t* s_read, uint32_t row_wor
 // bwt_smem1a_new (baseline.cpp:180-304), max_intv = 0, in its two halves.
 // Forward half (:193-218): extends q[x..] to the right, L.curr(0 .. n_curr) receives the interval in front of every change of
 // size; returns n_curr, *ret = where the next call of the first pass starts.
+// Are the SMEM_KTAB_L bases from x clean, and which table entry do they spell?  (q[x] < 4 is the caller's.)
+template <typename Q>
+__device__ __forceinline__ bool ktab_code(const Q& q, int x, int len, uint32_t& code) {
+  if (x + SMEM_KTAB_L > len) return false;
+  uint32_t c = (uint32_t)q[x];
+  bool ok = true;
+#pragma unroll
+  for (int j = 1; j < SMEM_KTAB_L; j++) { const int b = q[x + j]; ok = ok && b < 4; c = (c << 2) | (uint32_t)(b & 3); }
+  code = c;
+  return ok;
+}
+template <typename IT> __device__ __forceinline__ Intv<IT> ktab_entry(const uint4* tab, int L, uint32_t code);
+template <> __device__ __forceinline__ Intv<uint32_t> ktab_entry<uint32_t>(const uint4* tab, int L, uint32_t code) {
+  const uint4 e = tab[smem_ktab_off(L) + (code >> (2 * (SMEM_KTAB_L - L)))];
+  Intv<uint32_t> r; r.x0 = e.x; r.x1 = e.y; r.x2 = e.z; r.info = 0;
+  return r;
+}
+template <> __device__ __forceinline__ Intv<uint64_t> ktab_entry<uint64_t>(const uint4*, int, uint32_t) { Intv<uint64_t> r; r.x0 = r.x1 = r.x2 = 0; r.set(0, 0); return r; }
+
 template <typename IT, typename Q>
 __device__ __forceinline__ int smem1a_fwd(const Ctx<IT>& f, int len, const Q& q, int x, int min_intv, const Lists<IT>& L, int* ret) {
   typedef Intv<IT> I;
   if (min_intv < 1) min_intv = 1;
   I ik = set_intv1(f, q[x]);
   ik.set((uint32_t)(x + 1), 0);
-  int n_curr = 0, i;
-  for (i = x + 1; i < len; i++) {
-    if (q[i] < 4) {
-      const I nx = extend(f, ik, false, 3 - q[i]);
-      if (nx.x2 != ik.x2) { L.curr(n_curr++) = ik; if (nx.x2 < (IT)min_intv) break; }
-      ik = nx; ik.set((uint32_t)(i + 1), 0);
-    } else { L.curr(n_curr++) = ik; break; }
+  int n_curr = 0, i = x + 1;
+  bool done = false;
+  uint32_t code;
+  if (sizeof(IT) == 4 && f.ktab && ktab_code(q, x, len, code)) {
+    // the intervals of q[x .. x+2), ... q[x .. x+SMEM_KTAB_L) from the prefix table, all loads in flight together; then the loop
+    // body below for each of them (the same pushes: an entry holds exactly what the extension would have returned)
+    I e[SMEM_KTAB_L - 1];
+#pragma unroll
+    for (int j = 0; j < SMEM_KTAB_L - 1; j++) e[j] = ktab_entry<IT>(f.ktab, j + 2, code);
+#pragma unroll
+    for (int j = 0; j < SMEM_KTAB_L - 1; j++) {
+      if (!done) {
+        const I nx = e[j];
+        if (nx.x2 != ik.x2) { L.curr(n_curr++) = ik; done = nx.x2 < (IT)min_intv; }
+        if (!done) { ik = nx; ik.set((uint32_t)(i + 1), 0); i++; }
+      }
+    }
   }
-  if (i == len) L.curr(n_curr++) = ik;
+  if (!done) {
+    for (; i < len; i++) {
+      if (q[i] < 4) {
+        const I nx = extend(f, ik, false, 3 - q[i]);
+        if (nx.x2 != ik.x2) { L.curr(n_curr++) = ik; if (nx.x2 < (IT)min_intv) break; }
+        ik = nx; ik.set((uint32_t)(i + 1), 0);
+      } else { L.curr(n_curr++) = ik; break; }
+    }
+    if (i == len) L.curr(n_curr++) = ik;
+  }
   *ret = (int)L.curr(n_curr - 1).lo();
   return n_curr;
 }
@@ -213,7 +252,46 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
     if (n_back == 0 || stop - start >= 3) {
       n_back = 0;
       L.back(n_back++) = ik;
-      for (int k = x - 1; k >= 0; k--) {
+      int k = x - 1;
+      bool stopped = false;
+      // The interval of q[k .. ci.lo) is the prefix table's entry for that string whichever side it grew from, so while the match
+      // is shorter than SMEM_KTAB_L bases its backward extensions are independent table loads instead of a chain of lookups
+      // (an entry that is empty only has to say so: the loop leaves before it would keep one).
+      const int ell = (int)ci.lo() - x;                     // bases matched so far (a curr entry starts at x)
+      if (sizeof(IT) == 4 && f.ktab && ell < SMEM_KTAB_L && k >= 0) {
+        uint32_t code0 = 0;
+        for (int j = 0; j < ell; j++) code0 = (code0 << 2) | (uint32_t)(q[x + j] & 3);
+        // first the sizes alone (one register per step), all loads in flight: how many steps succeed
+        uint32_t sz[SMEM_KTAB_L - 1];
+        uint32_t code = code0;
+        int bad = SMEM_KTAB_L;                              // first step whose base is ambiguous or in front of the read
+#pragma unroll
+        for (int j = 1; j < SMEM_KTAB_L; j++) {
+          sz[j - 1] = 0;
+          if (ell + j <= SMEM_KTAB_L && j < bad) {
+            const int b = x - j >= 0 ? q[x - j] : 4;
+            if (b >= 4) bad = j;
+            else { code |= (uint32_t)b << (2 * (ell + j - 1)); sz[j - 1] = f.ktab[smem_ktab_off(ell + j) + code].z; }
+          }
+        }
+        int n_ok = 0;
+#pragma unroll
+        for (int j = 1; j < SMEM_KTAB_L; j++)
+          if (ell + j <= SMEM_KTAB_L && n_ok == j - 1 && j < bad && sz[j - 1] >= (uint32_t)min_intv) n_ok = j;
+        stopped = n_ok < SMEM_KTAB_L - ell;                 // the loop ended inside the table's range
+        // then the entries of the steps that did
+        code = code0;
+        for (int j = 1; j <= n_ok; j++) {
+          code |= (uint32_t)(q[x - j] & 3) << (2 * (ell + j - 1));
+          const uint4 t = f.ktab[smem_ktab_off(ell + j) + code];
+          ik.x0 = (IT)t.x; ik.x1 = (IT)t.y; ik.x2 = (IT)t.z;
+          ik.set(ci.lo(), ci.hi() | (uint32_t)(x - j));
+          L.back(n_back++) = ik;
+        }
+        k = x - n_ok - 1;
+      }
+      if (!stopped)
+      for (; k >= 0; k--) {
         if (q[k] >= 4) break;
         const I nx = extend(f, ik, true, q[k]);
         if (nx.x2 < (IT)min_intv) break;
@@ -269,7 +347,10 @@ __device__ int seed_strategy1(const Ctx<IT>& f, int len, const Q& q, int x, int 
   mem.x0 = mem.x1 = mem.x2 = 0; mem.set(0, 0);
   if (q[x] > 3) return x + 1;
   ik = set_intv1(f, q[x]);
-  for (int i = x + 1; i < len; i++) {
+  int i = x + 1;
+  uint32_t code;      // the first SMEM_KTAB_L - 1 extensions cannot report anything (min_len): their result comes from the prefix table
+  if (sizeof(IT) == 4 && f.ktab && SMEM_KTAB_L - 1 < min_len && ktab_code(q, x, len, code)) { ik = ktab_entry<IT>(f.ktab, SMEM_KTAB_L, code); i = x + SMEM_KTAB_L; }
+  for (; i < len; i++) {
     if (q[i] >= 4) return i + 1;
     const Intv<IT> nx = extend(f, ik, false, 3 - q[i]);
     if (nx.x2 < (IT)max_intv && i - x >= min_len) { mem = nx; mem.set((uint32_t)(i + 1), (uint32_t)x); return i + 1; }
@@ -279,14 +360,14 @@ __device__ int seed_strategy1(const Ctx<IT>& f, int len, const Q& q, int x, int 
 }
 
 #ifndef SMEM_WAVES_PER_EU
-#define SMEM_WAVES_PER_EU 5     // what the allocator reaches on its own (95 VGPRs); see DESIGN.md 4b for 6 and 8
+#define SMEM_WAVES_PER_EU 5     // what the allocator reaches on its own (86 VGPRs); capped to 80 for a sixth wavefront it spills and measures the same
 #endif
 template <typename IT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_PER_EU))) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;
-  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
@@ -335,7 +416,7 @@ __global__ __launch_bounds__(64) void smem_fwd_kernel(SmemArgs a, uint32_t read_
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;
-  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
@@ -381,7 +462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_P
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;
-  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
@@ -412,7 +493,7 @@ __global__ __launch_bounds__(64) void smem_pass3_kernel(SmemArgs a, uint32_t rea
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n_reads) return;
   const uint32_t rd = read_base + tid;
-  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
@@ -427,6 +508,8 @@ __global__ __launch_bounds__(64) void smem_pass3_kernel(SmemArgs a, uint32_t rea
     if (!inside) {
       if (q[x] > 3) { x++; continue; }
       ik = set_intv1(f, q[x]); i = x + 1; inside = true;
+      uint32_t code;  // (see seed_strategy1)
+      if (sizeof(IT) == 4 && f.ktab && ktab_code(q, x, len, code)) { ik = ktab_entry<IT>(f.ktab, SMEM_KTAB_L, code); i = x + SMEM_KTAB_L; }
     }
     if (i >= len) break;                                   // `return len`: nothing reported, the scan is over
     if (q[i] >= 4) { x = i + 1; inside = false; continue; }
@@ -466,7 +549,7 @@ __global__ __launch_bounds__(64) void smem_engine(SmemArgs a, uint32_t read_base
   typedef Intv<IT> I;
   constexpr int SLOW_BATCH = SMEM_SLOW_BATCH;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
@@ -641,7 +724,34 @@ __global__ __launch_bounds__(64) void smem_engine(SmemArgs a, uint32_t read_base
   }
 }
 
+// One level of the prefix table from the level above it, with the kernel's own bwt_extend (so that an entry is bit for bit what the
+// stepwise extension returns, empty intervals included).
+__global__ __launch_bounds__(256) void smem_ktab_kernel(SmemArgs a, uint4* tab, int L) {
+  const uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
+  if (code >= (1u << (2 * L))) return;
+  Ctx<uint32_t> f; f.bwt = a.bwt; f.primary = (uint32_t)a.primary; f.ktab = nullptr;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = (uint32_t)a.L2[c];
+  Intv<uint32_t> r;
+  if (L == 1) r = set_intv1(f, (int)code);
+  else {
+    const uint4 e = tab[smem_ktab_off(L - 1) + (code >> 2)];
+    Intv<uint32_t> p; p.x0 = e.x; p.x1 = e.y; p.x2 = e.z; p.info = 0;
+    r = extend(f, p, false, 3 - (int)(code & 3u));
+  }
+  tab[smem_ktab_off(L) + code] = make_uint4(r.x0, r.x1, r.x2, 0u);
+}
+
 }  // namespace
+
+hipError_t smem_build_ktab(const SmemArgs& a, uint4* ktab, hipStream_t s) {
+  if (!a.compact) return hipErrorInvalidValue;
+  for (int L = 1; L <= SMEM_KTAB_L; L++) {
+    const uint32_t n = 1u << (2 * L);
+    hipLaunchKernelGGL(smem_ktab_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, ktab, L);
+  }
+  return hipGetLastError();
+}
 
 hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
