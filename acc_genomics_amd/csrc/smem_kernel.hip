@@ -244,6 +244,7 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
   temp.x0 = temp.x1 = temp.x2 = 0; temp.set(0, 0);
   int n_back = 0, i;
   int start = x, stop = x, max_len = 0;
+  int k_try = -1, m_done = 0; // "forwardenlarge": the longest back entry that may still succeed, and how far it has been enlarged (in temp)
   i = 0;
   while (i < n_curr) {
     const I ci = L.curr(i);
@@ -303,12 +304,25 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
       stop = (i == n_curr - 1) ? len : (int)L.curr(i + 1).lo();
       if (i != 0 && ik.hi() > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
       temp = ik;
+      k_try = n_back - 1; m_done = start;
     } else {
+      // "forwardenlarge" (:255-281) tries the back entries from the longest one down until one can be enlarged to `stop`.  Between
+      // two "backenlarge" runs the back list and `start` stay as they are and `stop` only grows, and an entry that could not be
+      // enlarged to an earlier stop fails at the same base again: the search resumes at the entry that succeeded last time (k_try;
+      // nothing left to try if none did) -- the reference re-tries all the longer ones first, with the same outcome.  In the
+      // re-seeding pass that is a dozen failed attempts per list entry.
+      // ... and that entry's interval enlarged up to the earlier stop (m_done) is `temp` (the result it left there; right after a
+      // "backenlarge" run: the entry itself), so its attempt goes on from there instead of from the back list.
       stop = (int)ci.lo();
-      for (int k = n_back - 1; k >= 0; k--) {
-        ik = L.back(k);
+      int k = k_try;
+      bool resume = k >= 0;
+      k_try = -1;
+      for (; k >= 0; k--) {
+        int m = start + 1;
+        if (resume) { ik = temp; m = m_done + 1; resume = false; }
+        else ik = L.back(k);
         bool reached = false;
-        for (int m = start + 1; m <= stop; m++) {
+        for (; m <= stop; m++) {
           const I nx = extend(f, ik, false, 3 - q[m - 1]);
           if (nx.x2 < (IT)min_intv) break;
           ik = nx;
@@ -317,6 +331,7 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
         if (reached) {
           if ((uint32_t)(x - k) > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
           temp = ik;
+          k_try = k; m_done = stop;
           break;
         }
       }
