@@ -235,7 +235,24 @@ __device__ __forceinline__ int smem1a_fwd(const Ctx<IT>& f, int len, const Q& q,
   *ret = (int)L.curr(n_curr - 1).lo();
   return n_curr;
 }
-// Backward half (:219-299): over the n_curr entries of L.curr
+// Backward half (:219-299): over the n_curr entries of L.curr.
+//
+// What the reference does per list entry [x, end): find the longest backward extension [x - k, end) that still has min_intv
+// occurrences, report the previous winner (`temp`) if the new one starts later, and make the new one `temp`.  It has two ways to
+// find it: "backenlarge" (:224-253) extends the entry backwards base by base from x - 1 and rebuilds the back list (the
+// extensions of that entry by 0, 1, 2 ... bases), run for the first entry and whenever the end has moved 3 bases beyond the last
+// such run; "forwardenlarge" (:255-281) tries the back-list entries from the longest down, enlarging each forwards to the new
+// end, until one survives.  Both compute the same thing -- occurrence counts only fall when a string grows, so the k they find
+// is the largest k whose string [x - k, end) survives, and the interval of a string does not depend on how it was grown -- and
+// they differ only in what they write to `start` / `stop` afterwards (which steers the entries to come).  So this function
+// keeps the reference's decisions and bookkeeping and is free in HOW it finds k for an entry:
+//   * the search never tries an entry longer than the last winner (it failed for a shorter end already) and starts from the last
+//     winner's interval, already enlarged to the previous end (`temp`, `m_done`);
+//   * any entry is found by that search when its end is only a few bases beyond the last one and the last winner survives, and by
+//     the backward chain (with the prefix table for its first steps) when that is the shorter way -- the first entry, typically
+//     the last one, whose end is far out, and whenever the winner is lost and the back list is more than 3 bases behind;
+//   * otherwise entries shorter than the winner are enlarged from the back list of the last backward chain (`b_start`).
+// Measured on configs[4]: 13.5 -> 11.1 ms with the first point, -> see DESIGN.md 4b for the rest.
 template <typename IT, typename Q>
 __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int min_intv, Out& mem, const Lists<IT>& L, int n_curr) {
   typedef Intv<IT> I;
@@ -244,21 +261,58 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
   temp.x0 = temp.x1 = temp.x2 = 0; temp.set(0, 0);
   int n_back = 0, i;
   int start = x, stop = x, max_len = 0;
-  int k_try = -1, m_done = 0; // "forwardenlarge": the longest back entry that may still succeed, and how far it has been enlarged (in temp)
+  int k_try = -1, m_done = 0;  // the last winner's k, and the end its interval (`temp`) has been enlarged to
+  int b_start = x;             // end of the strings in the back list (set by the last backward chain)
   i = 0;
   while (i < n_curr) {
     const I ci = L.curr(i);
-    ik = ci;
-    ik.set(ci.lo(), ci.hi() | (uint32_t)x);
-    if (n_back == 0 || stop - start >= 3) {
+    const int end = (int)ci.lo();
+    const bool is_back = n_back == 0 || stop - start >= 3;        // the reference's choice: decides the bookkeeping below
+    const int ell = end - x;                                        // bases matched so far (a curr entry starts at x)
+    // which way is shorter: enlarging the last winner by end - m_done bases, or a chain of at most k_try + 1 backward steps of
+    // which the prefix table answers those that stay within SMEM_KTAB_L bases
+    bool chain = n_back == 0;
+    // (a list entry below the bound itself -- possible only for a first base rarer than the bound -- has no surviving extension at
+    // all: "forwardenlarge" finds nothing and leaves everything as it is, "backenlarge" keeps the entry as it stands)
+    const bool hopeless = !is_back && ci.x2 < (IT)min_intv;
+    if (!chain && !hopeless) {
+      const int by_table = (sizeof(IT) == 4 && f.ktab && ell < SMEM_KTAB_L) ? SMEM_KTAB_L - ell : 0;
+      const int chain_cost = k_try + 1 > by_table ? k_try + 1 - by_table : 1;
+      chain = end - m_done > chain_cost;
+    }
+    int k_found = -1;
+    if (!chain && !hopeless) {
+      // the last winner first, from where it stands; if it does not survive, the shorter ones from the back list -- unless that
+      // list is stale (its strings end more than 3 bases back, where the reference would have rebuilt it): then the chain
+      int k = k_try;
+      bool resume = true;
+      for (; k >= 0; k--) {
+        int m = b_start + 1;
+        if (resume) { ik = temp; m = m_done + 1; }
+        else ik = L.back(k);
+        bool reached = m > end;                              // (cannot happen: ends only grow)
+        for (; m <= end; m++) {
+          const I nx = extend(f, ik, false, 3 - q[m - 1]);
+          if (nx.x2 < (IT)min_intv) break;
+          ik = nx;
+          if (m == end) reached = true;
+        }
+        if (reached) { ik.set(ci.lo(), ci.hi() | (uint32_t)(x - k)); k_found = k; break; }
+        if (resume && end - b_start > 3) break;
+        resume = false;
+      }
+      if (k_found < 0) chain = true;
+    }
+    if (chain) {
+      ik = ci;
+      ik.set(ci.lo(), ci.hi() | (uint32_t)x);
       n_back = 0;
       L.back(n_back++) = ik;
       int k = x - 1;
       bool stopped = false;
-      // The interval of q[k .. ci.lo) is the prefix table's entry for that string whichever side it grew from, so while the match
+      // The interval of q[k .. end) is the prefix table's entry for that string whichever side it grew from, so while the match
       // is shorter than SMEM_KTAB_L bases its backward extensions are independent table loads instead of a chain of lookups
       // (an entry that is empty only has to say so: the loop leaves before it would keep one).
-      const int ell = (int)ci.lo() - x;                     // bases matched so far (a curr entry starts at x)
       if (sizeof(IT) == 4 && f.ktab && ell < SMEM_KTAB_L && k >= 0) {
         uint32_t code0 = 0;
         for (int j = 0; j < ell; j++) code0 = (code0 << 2) | (uint32_t)(q[x + j] & 3);
@@ -300,41 +354,16 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
         ik.set(ci.lo(), ci.hi() | (uint32_t)k);
         L.back(n_back++) = ik;
       }
-      start = (int)ci.lo();
-      stop = (i == n_curr - 1) ? len : (int)L.curr(i + 1).lo();
+      b_start = end;
+      k_found = n_back - 1;
+    }
+    // the reference's bookkeeping (:242-253 behind "backenlarge", :255 and :270-279 around "forwardenlarge")
+    if (is_back) { start = end; stop = (i == n_curr - 1) ? len : (int)L.curr(i + 1).lo(); }
+    else stop = end;
+    if (k_found >= 0) {
       if (i != 0 && ik.hi() > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
       temp = ik;
-      k_try = n_back - 1; m_done = start;
-    } else {
-      // "forwardenlarge" (:255-281) tries the back entries from the longest one down until one can be enlarged to `stop`.  Between
-      // two "backenlarge" runs the back list and `start` stay as they are and `stop` only grows, and an entry that could not be
-      // enlarged to an earlier stop fails at the same base again: the search resumes at the entry that succeeded last time (k_try;
-      // nothing left to try if none did) -- the reference re-tries all the longer ones first, with the same outcome.  In the
-      // re-seeding pass that is a dozen failed attempts per list entry.
-      // ... and that entry's interval enlarged up to the earlier stop (m_done) is `temp` (the result it left there; right after a
-      // "backenlarge" run: the entry itself), so its attempt goes on from there instead of from the back list.
-      stop = (int)ci.lo();
-      int k = k_try;
-      bool resume = k >= 0;
-      k_try = -1;
-      for (; k >= 0; k--) {
-        int m = start + 1;
-        if (resume) { ik = temp; m = m_done + 1; resume = false; }
-        else ik = L.back(k);
-        bool reached = false;
-        for (; m <= stop; m++) {
-          const I nx = extend(f, ik, false, 3 - q[m - 1]);
-          if (nx.x2 < (IT)min_intv) break;
-          ik = nx;
-          if (m == stop) { ik.set(ci.lo(), ci.hi() | (uint32_t)(x - k)); reached = true; }
-        }
-        if (reached) {
-          if ((uint32_t)(x - k) > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
-          temp = ik;
-          k_try = k; m_done = stop;
-          break;
-        }
-      }
+      k_try = k_found; m_done = end;
     }
     i++;
     if (i < n_curr) max_len = (int)temp.hi() + (int)L.curr(i).lo();
