@@ -292,8 +292,8 @@ def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
                                                   "unit": "G sectors/s", "frac": lookups_per_read * n_reads / (k_ms * 1e-3) / 1e9 / SMEM_SECTOR_PEAK_G,
                                                   "note": "the bound that binds: dependent pairs of random 32-byte sector reads out of a 64 MB table, "
                                                           "all 64 lanes active, measured by tools/ubench_random.hip on MI355X "
-                                                          "(profiles/r02_ubench_random.txt); algorithmic lookups (the reference's count): those that share a sector with their twin "
-                                                          "or are answered by the prefix table count here too"},
+                                                          "(profiles/r02_ubench_random.txt); algorithmic lookups (the reference's count): those that share a sector with their twin, "
+                                                          "are answered by the prefix table or belong to searches the kernel shortens count here too, so frac can exceed 1"},
                                "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
                                        "the path is bound by dependent lookups"},
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},
