@@ -160,7 +160,9 @@ void accg_sw_batch_destroy(accg_sw_batch* b);
 typedef struct accg_smem_index accg_smem_index;
 typedef struct accg_smem_batch accg_smem_batch;
 /* bwt_words = the caller's true uint32 count (a BWA index is generally not a whole number of 16-word blocks: the tail is
- * padded inside; nothing beyond bwt[bwt_words - 1] is read). */
+ * padded inside; nothing beyond bwt[bwt_words - 1] is read).  What the device holds is the library's business: below 2^32
+ * symbols the blocks are re-laid out (32-byte half-blocks of 32-bit counts + two bit planes) and a 22 MB table of the
+ * intervals of all strings of up to ten bases is built next to them; the intervals a batch returns are the same numbers. */
 int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para, accg_smem_index** out);
 /* Index construction for a synthetic genome (the reference loads an existing one with libbwa's bwa_idx_load,
  * smem/main.cpp:434; SURVEY.md 8f row 1 asks for a constructor of our own): text = genome ++ reverse complement, suffix
