@@ -48,11 +48,13 @@ def _oracle(bwt, para, seq, ln, max_out):
 
 @pytest.mark.parametrize("seed,glen,repeat,layout", [(11, 4000, False, "compact"), (12, 30000, True, "compact"), (13, 200000, True, "compact"),
                                                       (12, 30000, True, "bwa"), (14, 100000, True, "bwa"), (15, 60000, True, "engine"),
-                                                      (12, 30000, True, "split"), (16, 80000, True, "split-bwa")])
+                                                      (12, 30000, True, "split"), (16, 80000, True, "split-bwa"), (13, 200000, True, "compact-noktab")])
 def test_bit_exact_vs_oracle(ctx, seed, glen, repeat, layout, monkeypatch):
     """Both index layouts in HBM (the half-block re-layout done on upload, default, and BWA's own blocks) and both kernels."""
     if layout in ("bwa", "split-bwa"):
         monkeypatch.setenv("ACCG_SMEM_COMPACT", "0")
+    if layout == "compact-noktab":              # half-block index without the prefix table: every extension through bwt_extend
+        monkeypatch.setenv("ACCG_SMEM_KTAB", "0")
     if layout.startswith("split"):              # three-kernel form (forward / backward + re-seeding / third pass), off by default
         monkeypatch.setenv("ACCG_SMEM_SPLIT", "1")
     if layout == "engine":                      # persistent-wavefront state-machine variant (off by default)

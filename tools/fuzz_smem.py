@@ -36,8 +36,8 @@ for it in range(rounds):
     want = np.zeros((n, max_out, 4), np.uint64); wnum = np.zeros(n, np.int32)
     O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, n, max_out, want.ctypes.data, wnum.ctypes.data, 16)
     for env in ({}, {"ACCG_SMEM_COMPACT": "0"}, {"ACCG_SMEM_ENGINE": "1", "ACCG_SMEM_ENGINE_WAVES": "5"}, {"ACCG_SMEM_SPLIT": "1"},
-                {"ACCG_SMEM_SPLIT": "1", "ACCG_SMEM_COMPACT": "0"}):
-        for k in ("ACCG_SMEM_COMPACT", "ACCG_SMEM_ENGINE", "ACCG_SMEM_ENGINE_WAVES", "ACCG_SMEM_SPLIT"): os.environ.pop(k, None)
+                {"ACCG_SMEM_SPLIT": "1", "ACCG_SMEM_COMPACT": "0"}, {"ACCG_SMEM_KTAB": "0"}):
+        for k in ("ACCG_SMEM_COMPACT", "ACCG_SMEM_ENGINE", "ACCG_SMEM_ENGINE_WAVES", "ACCG_SMEM_SPLIT", "ACCG_SMEM_KTAB"): os.environ.pop(k, None)
         os.environ.update(env)
         with A.Context(0) as ctx, A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, max_out) as b:
             b.run(); got, gnum = b.results()
