@@ -808,7 +808,8 @@ hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, 
   const dim3 grid((n_reads + 63) / 64), block(64);
   const size_t row = (size_t)64 * a.read_words * sizeof(uint32_t);
   auto lds_for = [&](uint32_t waves_per_cu) {      // an LDS request that admits only this many wavefronts per CU (0: no limit)
-    return waves_per_cu ? std::max<size_t>(row, (160 * 1024 / waves_per_cu) & ~(size_t)255) : row;
+    // (never more than the 64 KB a launch may ask for without a function attribute: a limit below 3 wavefronts per CU is read as 3)
+    return waves_per_cu ? std::max<size_t>(row, std::min<size_t>(64 * 1024, (160 * 1024 / waves_per_cu) & ~(size_t)255)) : row;
   };
   if (a.seg) {         // three kernels (ACCG_SMEM_SPLIT=1)
     const size_t lds_f = lds_for(a.waves_per_cu ? a.waves_per_cu : 12), lds_b = lds_for(a.waves_per_cu);
