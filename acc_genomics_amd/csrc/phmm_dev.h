@@ -60,6 +60,8 @@ struct PhmmTables {
   T init;          // INITIAL_CONSTANT 2^120 | 2^1020  Context.h:109,149
 };
 
+struct PhmmHapDesc { uint32_t off, len, col, id; };   // offset and length of the bases in hblob, column in the region's output row, global hap index
+
 constexpr uint32_t PHMM_RESCUE_GRID_DEFAULT = 4096;
 template <typename T>
 struct PhmmArgs {
@@ -69,7 +71,7 @@ struct PhmmArgs {
   const uint32_t* rd_out;     // per read: index of out[read][hap 0]
   const SeqRef* hp;           // per hap
   const uint32_t* hp_local;   // per hap: column inside its region's output row
-  const uint32_t* hap_ids;    // job hap lists
+  const PhmmHapDesc* hap_desc;  // job hap lists, one descriptor per entry (what hp / hp_local hold for that haplotype: one level of loads less per job)
   const PhmmWork* work;
   T* out;
   const float* raw;           // rescue pass only: the fp32 results that decide which pairs are redone

@@ -264,7 +264,8 @@ struct accg_phmm_batch {
   size_t res_off = 0;            // arena offset of the results block [n_rescued u64][out f32 x (pairs+1)]
   DevBuf<uint8_t> d_rblob, d_hblob;
   DevBuf<SeqRef> d_rd, d_hp;
-  DevBuf<uint32_t> d_rd_out, d_hp_local, d_hap_ids;
+  DevBuf<uint32_t> d_rd_out, d_hp_local;
+  DevBuf<PhmmHapDesc> d_hap_desc;   // hap_ids with the haplotype's descriptor next to each id
   DevBuf<PhmmWork> d_work;
   DevBuf<float> d_out;
   DevBuf<double> d_out64;
@@ -571,7 +572,7 @@ template <typename T>
 PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab) {
   PhmmArgs<T> a;
   a.rblob = b.d_rblob.p; a.hblob = b.d_hblob.p; a.rd = b.d_rd.p; a.rd_out = b.d_rd_out.p; a.hp = b.d_hp.p;
-  a.hp_local = b.d_hp_local.p; a.hap_ids = b.d_hap_ids.p; a.work = b.d_work.p; a.out = out;
+  a.hp_local = b.d_hp_local.p; a.hap_desc = b.d_hap_desc.p; a.work = b.d_work.p; a.out = out;
   a.raw = b.d_out.p; a.n_rescued = reinterpret_cast<unsigned long long*>(b.d_state.p + state_nresc(b)); a.tab = tab;
   a.read_flag = b.d_state.p;
   a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0; a.job_count = nullptr; a.lds_min = 0;
@@ -699,7 +700,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   auto take = [&](size_t bytes, size_t align = 256) { off = (off + align - 1) / align * align; const size_t o = off; off += bytes; return o; };
   auto vbytes = [](const auto& v) { return v.size() * sizeof(v[0]); };
   const size_t o_rblob = take(roff + 16), o_hblob = take(hoff + 16), o_rd = take(vbytes(b->rd)), o_hp = take(vbytes(b->hp)),
-               o_rd_out = take(vbytes(b->rd_out)), o_hp_local = take(vbytes(b->hp_local)), o_hap_ids = take(vbytes(b->hap_ids)),
+               o_rd_out = take(vbytes(b->rd_out)), o_hp_local = take(vbytes(b->hp_local)), o_hap_ids = take(b->hap_ids.size() * sizeof(PhmmHapDesc)),
                o_work = take(vbytes(b->work)), o_regions = take(vbytes(b->regions_dev)), o_chunks = take(vbytes(b->chunks_dev)),
                o_sorted = take(vbytes(b->sorted_reads));
   const size_t upload_bytes = off;
@@ -715,7 +716,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_rblob.place(base, o_rblob, roff + 16); b->d_hblob.place(base, o_hblob, hoff + 16);
   b->d_rd.place(base, o_rd, b->rd.size()); b->d_hp.place(base, o_hp, b->hp.size());
   b->d_rd_out.place(base, o_rd_out, b->rd_out.size()); b->d_hp_local.place(base, o_hp_local, b->hp_local.size());
-  b->d_hap_ids.place(base, o_hap_ids, b->hap_ids.size()); b->d_work.place(base, o_work, b->work.size());
+  b->d_hap_desc.place(base, o_hap_ids, b->hap_ids.size()); b->d_work.place(base, o_work, b->work.size());
   b->d_regions.place(base, o_regions, b->regions_dev.size()); b->d_chunks.place(base, o_chunks, b->chunks_dev.size());
   b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
   b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
@@ -737,7 +738,11 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   }
   memset(stage + o_rblob + roff, 0, 16); memset(stage + o_hblob + hoff, 0, 16);
   auto put = [&](size_t o, const auto& v) { if (!v.empty()) memcpy(stage + o, v.data(), vbytes(v)); };
-  put(o_rd, b->rd); put(o_hp, b->hp); put(o_rd_out, b->rd_out); put(o_hp_local, b->hp_local); put(o_hap_ids, b->hap_ids);
+  put(o_rd, b->rd); put(o_hp, b->hp); put(o_rd_out, b->rd_out); put(o_hp_local, b->hp_local);
+  {
+    PhmmHapDesc* hd = reinterpret_cast<PhmmHapDesc*>(stage + o_hap_ids);
+    for (size_t i = 0; i < b->hap_ids.size(); i++) { const uint32_t g = b->hap_ids[i]; hd[i] = PhmmHapDesc{b->hp[g].off, b->hp[g].len, b->hp_local[g], g}; }
+  }
   put(o_work, b->work); put(o_regions, b->regions_dev); put(o_chunks, b->chunks_dev); put(o_sorted, b->sorted_reads);
   if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
   ACCG_HIP(hipMemsetAsync(base + o_out64, 0, (o_out - o_out64) + (b->pairs + 1) * sizeof(float), s));   // out64, state, out

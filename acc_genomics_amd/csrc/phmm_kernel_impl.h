@@ -411,12 +411,10 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   for (int i = lane; i < LPP - 1; i += 64) stream[i] = 0;
   // the haplotypes' descriptors, one per lane (a job lists at most PHMM_HAPS_MAX = 48): two latencies for all of them instead
   // of two per haplotype
-  uint32_t gh_l = 0, col_l = 0, hoff_l = 0, hlen_l = 0;
+  uint32_t col_l = 0, hoff_l = 0, hlen_l = 0;
   if (lane < n_list) {
-    gh_l = a.hap_ids[hap_off + lane];
-    col_l = a.hp_local[gh_l];
-    const SeqRef h_ = a.hp[gh_l];
-    hoff_l = h_.off; hlen_l = h_.len;
+    const PhmmHapDesc h_ = a.hap_desc[hap_off + lane];
+    col_l = h_.col; hoff_l = h_.off; hlen_l = h_.len;
   }
   for (int j = 0; j < n_list; j++) {
     const uint32_t col = __builtin_amdgcn_readlane(col_l, j);
