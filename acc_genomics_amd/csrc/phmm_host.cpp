@@ -423,10 +423,13 @@ void partition(accg_phmm_batch& b) {
       kw[Q.lpp == 8 ? 0 : Q.lpp == 16 ? 1 : Q.lpp == 32 ? 2 : 3][Q.K] += (uint64_t)r.n_haps;
     }
   }
-  int K_dom = 1, lpp_dom = 16;
+  int K_dom = 1, lpp_dom = 16, n_classes = 0;
   for (int li = 0; li < 4; li++)
-    for (int k = 1; k <= PHMM_MAX_K; k++)
+    for (int k = 1; k <= PHMM_MAX_K; k++) {
+      n_classes += kw[li][k] != 0;
       if (kw[li][k] > kw[lpp_dom == 8 ? 0 : lpp_dom == 16 ? 1 : lpp_dom == 32 ? 2 : 3][K_dom]) { K_dom = k; lpp_dom = 8 << li; }
+    }
+  n_classes = std::max(n_classes, 1);
 
   // candidate budgets: multiples of the most common haplotype length, plus a geometric ladder
   std::vector<uint64_t> cand;
@@ -503,7 +506,10 @@ void partition(accg_phmm_batch& b) {
       double span = loads.rbegin()->first * rate * w;
       // the hardware dispatcher is not an ideal list scheduler, and a slot that runs out of jobs early leaves its SIMD partner
       // alone at a quarter of the issue rate: a mild preference for several jobs per slot
-      span *= 1.0 + 0.05 * (double)slots / (double)n_jobs;
+      // ... and every (lanes, K) class is a launch of its own with a tail of its own, and the rescue pass inherits the chunking: with
+      // the ten classes of a configs[3] mix a 128-region shard ran 18 % faster on jobs a third the size this term used to pick
+      // (2.65 against 3.22 ms with the rescue; 1024 regions: the same choice as before)
+      span *= 1.0 + 0.05 * (double)n_classes * (double)slots / (double)n_jobs;
       // long streams cost LDS (occupancy of the launches with few rows per lane) and lengthen the tail of every launch: measured
       // on the configs[3] mix +1 % at 2048 entries and +4.5 % at 4096 against 1300 (tools/sweep_c3.sh)
       if (cap > 1300) span *= 1.0 + 0.03 * ((double)cap - 1300.0) / 1024.0;
