@@ -20,6 +20,8 @@ flip = rng.random(N) < 0.5
 reads[flip] = 3 - reads[flip][:, ::-1]
 m = rng.random(reads.shape) < 0.01
 reads[m] = rng.integers(0, 4, size=int(m.sum()))
+if os.environ.get("SMEM_SORT_READS") == "1":     # experiment: reads ordered by their number of substitutions (what a work-ordered launch would see)
+    reads = reads[np.argsort(m.sum(axis=1), kind="stable")]
 seq = np.zeros((N, 256), np.uint8); seq[:, :150] = reads
 ln = np.full(N, 150, np.uint8)
 with A.Context(0) as ctx, A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, 64) as b:
