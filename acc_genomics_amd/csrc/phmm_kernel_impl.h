@@ -273,7 +273,9 @@ __device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& 
   if (X6) {
     // Xs of row 0 of the lane to the right: the same single fma as inside a lane (nMX is 1, or 0 towards another read's lanes and
     // in a group's last lane: the product with it is exact); the last read row's M + X = M + pMX * Xs likewise
-    s.x_out = fma_(s.X[K - 1], s.nXX, s.M[K - 1] * s.nMX);
+    // (nMX is 1 in every lane but a group's last, whose hand-off nobody needs: what it passes to the first lane of the next read --
+    // its M -- lands in the X of a clone of row 0, which is multiplied by the clone's zero coefficients only.  So no product with nMX.)
+    s.x_out = fma_(s.X[K - 1], s.nXX, s.M[K - 1]);
     return fma_(s.X[K - 1], s.xl, s.M[K - 1]);
   }
   s.x_out = fma_(s.M[K - 1], s.nMX, s.X[K - 1] * s.nXX);
