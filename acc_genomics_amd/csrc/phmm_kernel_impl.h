@@ -157,6 +157,13 @@ __device__ __forceinline__ void column(Rows<T, K>& s, const T (&d)[K], bool carr
 // QT younger ones may still be in flight: s_waitcnt lgkmcnt(QT) everywhere.  (No scalar memory load may sit in this loop: SMEM
 // shares the counter and returns out of order.  tools/check_phmm_asm.py looks for one in the built code object.)
 template <int N> __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+// The same as an instruction the compiler knows (vmcnt 63, expcnt 7, lgkmcnt N in the gfx9 encoding).  Why it matters: the
+// hazard recognizer gives an inline-asm statement zero wait states and assumes the worst of what it writes (gfx950's forwarding
+// hazard of sub-dword writes), so between two asm statements of which the second reads a register of the first it puts an
+// s_nop -- one issue slot, and with two wavefronts per SIMD issue slots are what the sweep is short of.  A real instruction in
+// between (this one, at every quad boundary) makes that s_nop unnecessary; rows are issued two per asm statement for the same
+// reason (12 -> 3 s_nop per column at K = 13).
+template <int N> __device__ __forceinline__ void lgkm_wait_visible() { __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8)); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }   // low half of a flat LDS address = the LDS offset
 
 template <int REM> struct TailQuad;        // the last quad of a K that is not a multiple of four is loaded with its exact width
@@ -198,9 +205,83 @@ __device__ __forceinline__ void load_all_quads(DistRegs<K>& dq, unsigned addr, u
 template <int LPP, int K, bool X6, int Q>
 __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj, float& tc, float& a_new) {
   if constexpr (Q < DistRegs<K>::QT) {
-    lgkm_wait<DistRegs<K>::QT>();                      // this quad's values (loaded during the previous step) have landed
+    // this quad's values (loaded during the previous step) have landed: awaited at the top of the column for quad 0, and for
+    // every later quad BEFORE the reload of the quad in front of it is issued (one load less in flight at that point: QT - 1), so
+    // that the wait -- an instruction the compiler knows -- stands between the rows' asm statement and the load's
+    if constexpr (Q == 0) lgkm_wait_visible<DistRegs<K>::QT>();
+    constexpr int K0 = 4 * Q, K1 = (4 * Q + 4 < K) ? 4 * Q + 4 : K;     // rows of this quad
 #pragma unroll
-    for (int k = 4 * Q; k < 4 * Q + 4 && k < K; k++) {
+    for (int k = K0; k < K1; k++) {
+      if constexpr (X6) {
+        // two rows per asm statement (see lgkm_wait_visible): rows (k, k + 1) of the same quad, k even inside the quad
+        if ((k - K0) % 2 == 1) continue;                                   // done as the second row of the pair in front of it
+        if (k + 1 < K1) {
+          const float d0 = dq.get(k), d1 = dq.get(k + 1);
+          const float gn0 = s.pGM[k + 1], mn0 = s.pMM[k + 1];
+          const float gn1 = (k + 2 < K) ? s.pGM[k + 2] : s.nGM, mn1 = (k + 2 < K) ? s.pMM[k + 2] : s.nMM;
+          float t0, t1;
+          if (k == 0) {
+            if (LPP <= 16) {
+              asm volatile(
+                  "v_fma_f32 %[t0], %[X0], %[gn0], %[Y0]\n\t"
+                  "v_mul_f32 %[Y0], %[Y0], %[xx0]\n\t"
+                  "v_fmac_f32 %[t0], %[M0], %[mn0]\n\t"
+                  "v_fmac_f32 %[Y0], %[M0], %[my0]\n\t"
+                  "v_mov_b32_dpp %[X0], %[xo] " ACCG_DPP_ROW "\n\t"
+                  "v_mul_f32_dpp %[M0], %[ao], %[d0] " ACCG_DPP_ROW "\n\t"
+                  "v_fma_f32 %[t1], %[X1], %[gn1], %[Y1]\n\t"
+                  "v_mul_f32 %[Y1], %[Y1], %[xx1]\n\t"
+                  "v_fma_f32 %[X1], %[X0], %[mx1], %[M0]\n\t"
+                  "v_fmac_f32 %[t1], %[M1], %[mn1]\n\t"
+                  "v_fmac_f32 %[Y1], %[M1], %[my1]\n\t"
+                  "v_mul_f32 %[M1], %[d1], %[t0]"
+                  : [t0] "=&v"(t0), [t1] "=&v"(t1), [X0] "+v"(s.X[0]), [Y0] "+v"(s.Y[0]), [M0] "+v"(s.M[0]), [X1] "+v"(s.X[1]), [Y1] "+v"(s.Y[1]),
+                    [M1] "+v"(s.M[1])
+                  : [gn0] "v"(gn0), [xx0] "v"(s.pXX[0]), [mn0] "v"(mn0), [my0] "v"(s.pMY[0]), [xo] "v"(s.x_out), [ao] "v"(s.a_out), [d0] "v"(d0),
+                    [gn1] "v"(gn1), [xx1] "v"(s.pXX[1]), [mn1] "v"(mn1), [my1] "v"(s.pMY[1]), [mx1] "v"(s.pMX[1]), [d1] "v"(d1));
+            } else {
+              asm volatile(
+                  "v_fma_f32 %[t0], %[X0], %[gn0], %[Y0]\n\t"
+                  "v_mul_f32 %[Y0], %[Y0], %[xx0]\n\t"
+                  "v_fmac_f32 %[t0], %[M0], %[mn0]\n\t"
+                  "v_fmac_f32 %[Y0], %[M0], %[my0]\n\t"
+                  "v_mov_b32_dpp %[X0], %[xo] " ACCG_DPP_WAVE "\n\t"
+                  "v_mul_f32_dpp %[M0], %[ao], %[d0] " ACCG_DPP_WAVE "\n\t"
+                  "v_fma_f32 %[t1], %[X1], %[gn1], %[Y1]\n\t"
+                  "v_mul_f32 %[Y1], %[Y1], %[xx1]\n\t"
+                  "v_fma_f32 %[X1], %[X0], %[mx1], %[M0]\n\t"
+                  "v_fmac_f32 %[t1], %[M1], %[mn1]\n\t"
+                  "v_fmac_f32 %[Y1], %[M1], %[my1]\n\t"
+                  "v_mul_f32 %[M1], %[d1], %[t0]"
+                  : [t0] "=&v"(t0), [t1] "=&v"(t1), [X0] "+v"(s.X[0]), [Y0] "+v"(s.Y[0]), [M0] "+v"(s.M[0]), [X1] "+v"(s.X[1]), [Y1] "+v"(s.Y[1]),
+                    [M1] "+v"(s.M[1])
+                  : [gn0] "v"(gn0), [xx0] "v"(s.pXX[0]), [mn0] "v"(mn0), [my0] "v"(s.pMY[0]), [xo] "v"(s.x_out), [ao] "v"(s.a_out), [d0] "v"(d0),
+                    [gn1] "v"(gn1), [xx1] "v"(s.pXX[1]), [mn1] "v"(mn1), [my1] "v"(s.pMY[1]), [mx1] "v"(s.pMX[1]), [d1] "v"(d1));
+            }
+          } else {
+            asm volatile(
+                "v_fma_f32 %[t0], %[X0], %[gn0], %[Y0]\n\t"
+                "v_mul_f32 %[Y0], %[Y0], %[xx0]\n\t"
+                "v_fma_f32 %[X0], %[Xp], %[mx0], %[Mp]\n\t"
+                "v_fmac_f32 %[t0], %[M0], %[mn0]\n\t"
+                "v_fmac_f32 %[Y0], %[M0], %[my0]\n\t"
+                "v_mul_f32 %[M0], %[d0], %[tc]\n\t"
+                "v_fma_f32 %[t1], %[X1], %[gn1], %[Y1]\n\t"
+                "v_mul_f32 %[Y1], %[Y1], %[xx1]\n\t"
+                "v_fma_f32 %[X1], %[X0], %[mx1], %[M0]\n\t"
+                "v_fmac_f32 %[t1], %[M1], %[mn1]\n\t"
+                "v_fmac_f32 %[Y1], %[M1], %[my1]\n\t"
+                "v_mul_f32 %[M1], %[d1], %[t0]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [X0] "+v"(s.X[k]), [Y0] "+v"(s.Y[k]), [M0] "+v"(s.M[k]), [X1] "+v"(s.X[k + 1]),
+                  [Y1] "+v"(s.Y[k + 1]), [M1] "+v"(s.M[k + 1])
+                : [gn0] "v"(gn0), [xx0] "v"(s.pXX[k]), [mn0] "v"(mn0), [my0] "v"(s.pMY[k]), [mx0] "v"(s.pMX[k]), [d0] "v"(d0),
+                  [Xp] "v"(s.X[k - 1]), [Mp] "v"(s.M[k - 1]), [tc] "v"(tc),
+                  [gn1] "v"(gn1), [xx1] "v"(s.pXX[k + 1]), [mn1] "v"(mn1), [my1] "v"(s.pMY[k + 1]), [mx1] "v"(s.pMX[k + 1]), [d1] "v"(d1));
+          }
+          if (k + 2 < K) tc = t1; else a_new = t1;
+          continue;
+        }
+      }
       const float dk = dq.get(k);
       const float gn = (k + 1 < K) ? s.pGM[k + 1] : s.nGM;
       const float mn = (k + 1 < K) ? s.pMM[k + 1] : s.nMM;
@@ -259,6 +340,7 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
       }
       if (k + 1 < K) tc = tn; else a_new = tn;
     }
+    if constexpr (Q + 1 < DistRegs<K>::QT) lgkm_wait_visible<DistRegs<K>::QT - 1>();
     dq.template load<Q>(addr_next, tail_adj);          // the same registers, for the next step
     column_rows<LPP, K, X6, Q + 1>(s, dq, addr_next, tail_adj, tc, a_new);
   }
