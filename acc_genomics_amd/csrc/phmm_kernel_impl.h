@@ -189,6 +189,14 @@ struct DistRegs {
   typename TailQuad<REM ? REM : 4>::type tail;
   __device__ __forceinline__ float get(int k) const { return k / 4 < FULL ? q[k / 4][k % 4] : quad_elem<REM ? REM : 4>(tail, k % 4); }
   // addr = slab + lane * 16; the tail's rows sit at FULL * 1024 + lane * phmm_tail_stride(K): tail_adj = lane * (stride - 16)
+  // A use of every register (no instruction): behind the sweep loop, so that the registers count as live on the loop's exit path
+  // too -- the loads of the step that is never run are still in flight there, and a register the compiler took for dead would be
+  // handed to other code while its load is on the way.
+  __device__ __forceinline__ void keep() const {
+#pragma unroll
+    for (int i = 0; i < (FULL > 0 ? FULL : 0); i++) asm volatile("" ::"v"(q[i]));
+    if constexpr (REM != 0) asm volatile("" ::"v"(tail));
+  }
   template <int Q> __device__ __forceinline__ void load(unsigned addr, unsigned tail_adj) {
     if constexpr (Q < FULL) lds_load_quad<4, Q * 1024>(q[Q], addr);
     else if constexpr (REM == 3 || REM == 0) lds_load_quad<REM ? REM : 4, Q * 1024>(tail, addr);
@@ -375,6 +383,11 @@ struct DistRegsD {
   d2v q[FULL > 0 ? FULL : 1];
   double tail;
   __device__ __forceinline__ double get(int k) const { return k / 2 < FULL ? q[k / 2][k % 2] : tail; }
+  __device__ __forceinline__ void keep() const {         // see DistRegs::keep
+#pragma unroll
+    for (int i = 0; i < (FULL > 0 ? FULL : 0); i++) asm volatile("" ::"v"(q[i]));
+    if constexpr (K % 2 != 0) asm volatile("" ::"v"(tail));
+  }
   template <int Q> __device__ __forceinline__ void load(unsigned addr, unsigned tail_adj) {
     if constexpr (Q < FULL) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[Q]) : "v"(addr), "n"(Q * 1024));
     else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tail) : "v"(addr + tail_adj), "n"(Q * 1024));
@@ -510,7 +523,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     }
     const SeqRef hr = {(uint32_t)__builtin_amdgcn_readlane(hoff_l, j), (uint32_t)__builtin_amdgcn_readlane(hlen_l, j)};
     if (lane == 0) {
-      stream[LPP - 1 + pos] = 0;
+      stream[LPP - 1 + pos] = (uint8_t)a.nchar;            // a bubble: the slab index one beyond the tables (its values are never kept)
       bpos[n_haps] = pos;
       y0s[n_haps] = a.tab.init / (T)(int)hr.len;     // baseline_impl.cpp:63
       hcol[n_haps] = col;
@@ -532,7 +545,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     if (lane == 0 && count_rescued) atomicAdd(a.n_rescued, (unsigned long long)n_flag);
   }
   if (lane == 0) { bpos[n_haps] = pos; bpos[n_haps + 1] = 0x7FFFFFFF; y0s[n_haps] = T(0); hcol[n_haps] = 0; }
-  for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = 0;   // terminal bubble + drain + prefetch slack
+  for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = i == 0 ? (uint8_t)a.nchar : (uint8_t)0;   // terminal bubble + drain + prefetch slack
   const int t_end = __builtin_amdgcn_readfirstlane(pos + LPP);         // the last lane passes the terminal bubble at pos+LPP-1
 #ifdef PHMM_TIMING
   __builtin_amdgcn_s_waitcnt(0);
@@ -687,9 +700,16 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     const unsigned slab_s = __builtin_amdgcn_readfirstlane((int)SLAB);
     const unsigned tail_adj = (unsigned)lane * (unsigned)(phmm_tail_stride(K, (int)sizeof(T)) - 16);     // wraps: lane * stride - lane * 16
     unsigned o1n, addr_next;  // stream byte in flight; LDS address of the next step's slab for this lane
+    // Which lanes are on a bubble (column 0 of their next haplotype) this step: read off the stream byte itself -- a bubble carries
+    // the marker nchar -- by the v_cmp that rides along with the slab address of the byte, one step ahead.  (Kept as scalar
+    // bookkeeping -- a mask shifted every step, a compare with the next bubble's position -- this cost six SALU instructions and
+    // two branches per step, and issue slots are what the sweep is short of.)
+    unsigned any_b, any_next;   // does any lane meet a bubble this step / the next one
+    const unsigned nchar_s = __builtin_amdgcn_readfirstlane((int)a.nchar);
     {
       // step 0's values (its slab index read and awaited on the spot), then the steady-state order: U, L0 .. L(QT-1)
-      asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_mad_u32_u24 %0, %0, %2, %3" : "=&v"(addr_next) : "v"(hs_a), "s"(slab_s), "v"(tab_a));
+      asm volatile("ds_read_u8 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_cmp_eq_u32 vcc, %5, %0\n\ts_or_b32 %1, vcc_lo, vcc_hi\n\tv_mad_u32_u24 %0, %0, %3, %4"
+                   : "=&v"(addr_next), "=&s"(any_b) : "v"(hs_a), "s"(slab_s), "v"(tab_a), "s"(nchar_s) : "vcc", "scc");
       asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(o1n) : "v"(hs_a));
       load_all_quads<K>(dq, addr_next, tail_adj, std::make_integer_sequence<int, NLD>{});
     }
@@ -705,22 +725,24 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       const unsigned hs_t = hs_a + (unsigned)t;
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        rm = (rm << 1) & (LPP == 64 ? ~0ull : ((1ull << (LPP & 63)) - 1));
-        if (__builtin_expect(t + u == nb, 0)) { rm |= 1ull; jn++; nb = __builtin_amdgcn_readfirstlane((int)bpos[jn]); }
-        // the stream byte issued one step ago has landed: address of the next step's slab, next byte on its way
-        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "n"(NLD));
+        // the stream byte issued one step ago has landed: address of the next step's slab and its bubble flag, next byte on its way
+        asm volatile("s_waitcnt lgkmcnt(%6)\n\tv_cmp_eq_u32 vcc, %5, %2\n\ts_or_b32 %1, vcc_lo, vcc_hi\n\tv_mad_u32_u24 %0, %2, %3, %4"
+                     : "=v"(addr_next), "=s"(any_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "s"(nchar_s), "n"(NLD) : "vcc", "scc");
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
         T contrib = AsmCol<T, K>::template column<LPP, X6>(s, dq, addr_next, tail_adj);
-        // Is any lane on a bubble?  Asked of the scalar unit through an opaque instruction: left to itself the compiler folds
-        // this test into the per-lane one below and pays three vector instructions and an EXEC round trip on every step.
-        unsigned any_bubble;
-        asm volatile("s_or_b32 %0, %1, %2" : "=s"(any_bubble) : "s"((unsigned)rm), "s"((unsigned)(rm >> 32)) : "scc");
-        if (__builtin_expect(any_bubble != 0, 0)) {
-          asm volatile("; bubble step");     // keeps this block from being merged into the per-lane test below
+        if (__builtin_expect(any_b != 0, 0)) {
+          // Off the hot path: first let every load this wave has in flight land.  The code below is the compiler's, which takes
+          // the asm loads' destination registers for written the moment the asm statement is through -- on the loop's exit path,
+          // where they are dead, it reuses one as an address register while the load is still on its way (tools/check_phmm_asm.py).
+          // (the step index and the lane's haplotype counter pass through the statement, so that nothing below -- all of it hangs on
+          // one of the two -- is scheduled in front of the wait)
+          int tu = t + u;
+          asm volatile("; bubble step\n\ts_waitcnt lgkmcnt(0)" : "+s"(tu), "+v"(jl));
           // Some lane (one per group) is on a bubble = column 0 of its next haplotype.  Everybody ran the ordinary column; that
           // lane now overwrites its state with the column-0 border (M = X = 0, Y = 0, clones of row 0: Y = INIT/H;
-          // baseline_impl.cpp:60-70) under EXEC.
-          if ((rm >> l) & 1ull) {
+          // baseline_impl.cpp:60-70) under EXEC.  Which lane: the one whose own stream byte of this step is the marker (read again
+          // here, off the hot path).
+          if (hs[tu] == (uint8_t)nchar_s) {
             if (l == LPP - 1 && jl >= 0 && have) {                                       // haplotype jl is complete
               a.out[out_base + hcol[jl]] = s.acc;
               if (RESCUE && s.acc < (T)PHMM_F64_TINY) tiny = true;
@@ -739,9 +761,12 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
           }
         }
         s.acc = s.acc + contrib;
+        any_b = any_next;
       }
       t += U;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(o1n));     // the loads issued for the step behind the last one (see DistRegs::keep)
+    dq.keep();
 #ifdef PHMM_TIMING
     if (lane == 0) { const unsigned long long tm2 = __builtin_amdgcn_s_memtime(); atomicAdd(&g_phmm_t[0], 1ull); atomicAdd(&g_phmm_t[1], tm1 - tm0); atomicAdd(&g_phmm_t[2], tm2 - tm1); atomicAdd(&g_phmm_t[3], tmA - tm0); atomicAdd(&g_phmm_t[4], tmB - tmA); atomicAdd(&g_phmm_t[5], tmC - tmB); atomicAdd(&g_phmm_t[6], tm1 - tmC); }
 #endif
