@@ -218,6 +218,52 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
     // that the wait -- an instruction the compiler knows -- stands between the rows' asm statement and the load's
     if constexpr (Q == 0) lgkm_wait_visible<DistRegs<K>::QT>();
     constexpr int K0 = 4 * Q, K1 = (4 * Q + 4 < K) ? 4 * Q + 4 : K;     // rows of this quad
+    if constexpr (X6 && K1 - K0 == 4) {
+      // a whole quad of rows in ONE asm statement (see lgkm_wait_visible: every boundary between two asm statements costs an issue
+      // slot, an s_nop or a wait; a quad boundary needs its wait anyway)
+#define ACCG_ROW6(n, xp, mp, tcin)                                                       \
+  "v_fma_f32 %[t" #n "], %[X" #n "], %[gn" #n "], %[Y" #n "]\n\t"                        \
+  "v_mul_f32 %[Y" #n "], %[Y" #n "], %[xx" #n "]\n\t"                                    \
+  "v_fma_f32 %[X" #n "], %[" xp "], %[mx" #n "], %[" mp "]\n\t"                          \
+  "v_fmac_f32 %[t" #n "], %[M" #n "], %[mn" #n "]\n\t"                                   \
+  "v_fmac_f32 %[Y" #n "], %[M" #n "], %[my" #n "]\n\t"                                   \
+  "v_mul_f32 %[M" #n "], %[d" #n "], %[" tcin "]\n\t"
+#define ACCG_ROW0(dpp)                                                                   \
+  "v_fma_f32 %[t0], %[X0], %[gn0], %[Y0]\n\t"                                           \
+  "v_mul_f32 %[Y0], %[Y0], %[xx0]\n\t"                                                  \
+  "v_fmac_f32 %[t0], %[M0], %[mn0]\n\t"                                                 \
+  "v_fmac_f32 %[Y0], %[M0], %[my0]\n\t"                                                 \
+  "v_mov_b32_dpp %[X0], %[xo] " dpp "\n\t"                                              \
+  "v_mul_f32_dpp %[M0], %[ao], %[d0] " dpp "\n\t"
+#define ACCG_QUAD_OUT                                                                                                        \
+  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [X0] "+v"(s.X[K0]), [Y0] "+v"(s.Y[K0]), [M0] "+v"(s.M[K0]),   \
+      [X1] "+v"(s.X[K0 + 1]), [Y1] "+v"(s.Y[K0 + 1]), [M1] "+v"(s.M[K0 + 1]), [X2] "+v"(s.X[K0 + 2]), [Y2] "+v"(s.Y[K0 + 2]),   \
+      [M2] "+v"(s.M[K0 + 2]), [X3] "+v"(s.X[K0 + 3]), [Y3] "+v"(s.Y[K0 + 3]), [M3] "+v"(s.M[K0 + 3])
+#define ACCG_QUAD_IN                                                                                                         \
+  [gn0] "v"(s.pGM[K0 + 1]), [gn1] "v"(s.pGM[K0 + 2]), [gn2] "v"(s.pGM[K0 + 3]), [gn3] "v"(gn3), [mn0] "v"(s.pMM[K0 + 1]),      \
+      [mn1] "v"(s.pMM[K0 + 2]), [mn2] "v"(s.pMM[K0 + 3]), [mn3] "v"(mn3), [xx0] "v"(s.pXX[K0]), [xx1] "v"(s.pXX[K0 + 1]),       \
+      [xx2] "v"(s.pXX[K0 + 2]), [xx3] "v"(s.pXX[K0 + 3]), [my0] "v"(s.pMY[K0]), [my1] "v"(s.pMY[K0 + 1]), [my2] "v"(s.pMY[K0 + 2]), \
+      [my3] "v"(s.pMY[K0 + 3]), [mx1] "v"(s.pMX[K0 + 1]), [mx2] "v"(s.pMX[K0 + 2]), [mx3] "v"(s.pMX[K0 + 3]), [d0] "v"(dq.get(K0)), \
+      [d1] "v"(dq.get(K0 + 1)), [d2] "v"(dq.get(K0 + 2)), [d3] "v"(dq.get(K0 + 3))
+      const float gn3 = (K0 + 4 < K) ? s.pGM[K0 + 4] : s.nGM, mn3 = (K0 + 4 < K) ? s.pMM[K0 + 4] : s.nMM;
+      float t0, t1, t2, t3;
+      if constexpr (Q == 0) {
+        if (LPP <= 16)
+          asm volatile(ACCG_ROW0(ACCG_DPP_ROW) ACCG_ROW6(1, "X0", "M0", "t0") ACCG_ROW6(2, "X1", "M1", "t1") ACCG_ROW6(3, "X2", "M2", "t2")
+                       : ACCG_QUAD_OUT : ACCG_QUAD_IN, [xo] "v"(s.x_out), [ao] "v"(s.a_out));
+        else
+          asm volatile(ACCG_ROW0(ACCG_DPP_WAVE) ACCG_ROW6(1, "X0", "M0", "t0") ACCG_ROW6(2, "X1", "M1", "t1") ACCG_ROW6(3, "X2", "M2", "t2")
+                       : ACCG_QUAD_OUT : ACCG_QUAD_IN, [xo] "v"(s.x_out), [ao] "v"(s.a_out));
+      } else {
+        asm volatile(ACCG_ROW6(0, "Xp", "Mp", "tc") ACCG_ROW6(1, "X0", "M0", "t0") ACCG_ROW6(2, "X1", "M1", "t1") ACCG_ROW6(3, "X2", "M2", "t2")
+                     : ACCG_QUAD_OUT : ACCG_QUAD_IN, [mx0] "v"(s.pMX[K0]), [Xp] "v"(s.X[K0 - 1]), [Mp] "v"(s.M[K0 - 1]), [tc] "v"(tc));
+      }
+#undef ACCG_ROW6
+#undef ACCG_ROW0
+#undef ACCG_QUAD_OUT
+#undef ACCG_QUAD_IN
+      if (K0 + 4 < K) tc = t3; else a_new = t3;
+    } else {
 #pragma unroll
     for (int k = K0; k < K1; k++) {
       if constexpr (X6) {
@@ -347,6 +393,7 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
               [mx] "v"(s.pMX[k]), [d] "v"(dk), [tc] "v"(tc));
       }
       if (k + 1 < K) tc = tn; else a_new = tn;
+    }
     }
     if constexpr (Q + 1 < DistRegs<K>::QT) lgkm_wait_visible<DistRegs<K>::QT - 1>();
     dq.template load<Q>(addr_next, tail_adj);          // the same registers, for the next step
