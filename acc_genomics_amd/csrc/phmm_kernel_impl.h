@@ -755,8 +755,10 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     const unsigned nchar_s = __builtin_amdgcn_readfirstlane((int)a.nchar);
     {
       // step 0's values (its slab index read and awaited on the spot), then the steady-state order: U, L0 .. L(QT-1)
-      asm volatile("ds_read_u8 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_cmp_eq_u32 vcc, %5, %0\n\ts_or_b32 %1, vcc_lo, vcc_hi\n\tv_mad_u32_u24 %0, %0, %3, %4"
-                   : "=&v"(addr_next), "=&s"(any_b) : "v"(hs_a), "s"(slab_s), "v"(tab_a), "s"(nchar_s) : "vcc", "scc");
+      unsigned b0;
+      asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b0) : "v"(hs_a));
+      asm volatile("v_cmp_eq_u32 vcc, %2, %1\n\ts_or_b32 %0, vcc_lo, vcc_hi" : "=s"(any_b) : "v"(b0), "s"(nchar_s) : "vcc", "scc");
+      asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(b0), "s"(slab_s), "v"(tab_a));
       asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(o1n) : "v"(hs_a));
       load_all_quads<K>(dq, addr_next, tail_adj, std::make_integer_sequence<int, NLD>{});
     }
@@ -773,10 +775,14 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
       for (int u = 0; u < U; u++) {
         // the stream byte issued one step ago has landed: address of the next step's slab and its bubble flag, next byte on its way
-        asm volatile("s_waitcnt lgkmcnt(%6)\n\tv_cmp_eq_u32 vcc, %5, %2\n\ts_or_b32 %1, vcc_lo, vcc_hi\n\tv_mad_u32_u24 %0, %2, %3, %4"
-                     : "=v"(addr_next), "=s"(any_next) : "v"(o1n), "s"(slab_s), "v"(tab_a), "s"(nchar_s), "n"(NLD) : "vcc", "scc");
+        // (two statements: with a vector and a scalar output in one the compiler no longer takes the scalar for uniform and tests it
+        // with a v_cmp and an EXEC mask)
+        asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_cmp_eq_u32 vcc, %3, %1\n\ts_or_b32 %0, vcc_lo, vcc_hi" : "=s"(any_next) : "v"(o1n), "n"(NLD), "s"(nchar_s) : "vcc", "scc");
+        asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a));
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
-        T contrib = AsmCol<T, K>::template column<LPP, X6>(s, dq, addr_next, tail_adj);
+        const T contrib = AsmCol<T, K>::template column<LPP, X6>(s, dq, addr_next, tail_adj);
+        const T acc_done = s.acc;            // the running sum up to the step before: what a bubble lane reports
+        s.acc = s.acc + contrib;             // (added before the branch: a bubble lane overwrites the sum, there is no second value of contrib to merge)
         if (__builtin_expect(any_b != 0, 0)) {
           // Off the hot path: first let every load this wave has in flight land.  The code below is the compiler's, which takes
           // the asm loads' destination registers for written the moment the asm statement is through -- on the loop's exit path,
@@ -791,9 +797,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
           // here, off the hot path).
           if (hs[tu] == (uint8_t)nchar_s) {
             if (l == LPP - 1 && jl >= 0 && have) {                                       // haplotype jl is complete
-              a.out[out_base + hcol[jl]] = s.acc;
-              if (RESCUE && s.acc < (T)PHMM_F64_TINY) tiny = true;
-              if (!RESCUE && sizeof(T) == 4 && a.read_flag && s.acc < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
+              a.out[out_base + hcol[jl]] = acc_done;
+              if (RESCUE && acc_done < (T)PHMM_F64_TINY) tiny = true;
+              if (!RESCUE && sizeof(T) == 4 && a.read_flag && acc_done < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
             }
             jl++;
             const T y0 = y0s[jl];
@@ -804,10 +810,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
             }
             s.x_out = T(0);
             s.acc = T(0);
-            contrib = T(0);
           }
         }
-        s.acc = s.acc + contrib;
         any_b = any_next;
       }
       t += U;
