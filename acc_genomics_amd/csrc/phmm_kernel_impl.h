@@ -216,7 +216,7 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
     // this quad's values (loaded during the previous step) have landed: awaited at the top of the column for quad 0, and for
     // every later quad BEFORE the reload of the quad in front of it is issued (one load less in flight at that point: QT - 1), so
     // that the wait -- an instruction the compiler knows -- stands between the rows' asm statement and the load's
-    if constexpr (Q == 0) lgkm_wait_visible<DistRegs<K>::QT>();
+    // (quad 0: awaited together with the stream byte at the top of the step, in the sweep loop)
     constexpr int K0 = 4 * Q, K1 = (4 * Q + 4 < K) ? 4 * Q + 4 : K;     // rows of this quad
     if constexpr (X6 && K1 - K0 == 4) {
       // a whole quad of rows in ONE asm statement (see lgkm_wait_visible: every boundary between two asm statements costs an issue
@@ -777,7 +777,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         // the stream byte issued one step ago has landed: address of the next step's slab and its bubble flag, next byte on its way
         // (two statements: with a vector and a scalar output in one the compiler no longer takes the scalar for uniform and tests it
         // with a v_cmp and an EXEC mask)
-        asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_cmp_eq_u32 vcc, %3, %1\n\ts_or_b32 %0, vcc_lo, vcc_hi" : "=s"(any_next) : "v"(o1n), "n"(NLD), "s"(nchar_s) : "vcc", "scc");
+        // (the wait also covers the first quad of dist values, the load right behind the byte: NLD - 1 younger ones may be in flight)
+        asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_cmp_eq_u32 vcc, %3, %1\n\ts_or_b32 %0, vcc_lo, vcc_hi" : "=s"(any_next) : "v"(o1n), "n"(NLD - 1), "s"(nchar_s) : "vcc", "scc");
         asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a));
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
         const T contrib = AsmCol<T, K>::template column<LPP, X6>(s, dq, addr_next, tail_adj);
