@@ -412,8 +412,11 @@ __device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& 
     // in a group's last lane: the product with it is exact); the last read row's M + X = M + pMX * Xs likewise
     // (nMX is 1 in every lane but a group's last, whose hand-off nobody needs: what it passes to the first lane of the next read --
     // its M -- lands in the X of a clone of row 0, which is multiplied by the clone's zero coefficients only.  So no product with nMX.)
-    s.x_out = fma_(s.X[K - 1], s.nXX, s.M[K - 1]);
-    return fma_(s.X[K - 1], s.xl, s.M[K - 1]);
+    // (in assembly: from C the compiler makes this fma a copy of M and an fmac into the copy -- one more issue slot per step)
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(s.x_out) : "v"(s.X[K - 1]), "v"(s.nXX), "v"(s.M[K - 1]));
+    float contrib;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(contrib) : "v"(s.X[K - 1]), "v"(s.xl), "v"(s.M[K - 1]));
+    return contrib;
   }
   s.x_out = fma_(s.M[K - 1], s.nMX, s.X[K - 1] * s.nXX);
   return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;   // 16 / 64 lanes: the last lane has nMX = nXX = 1, x_out = M + X
