@@ -34,9 +34,14 @@ Rccl* rccl() {
   Rccl& r = g_rccl;
   static std::once_flag once;
   std::call_once(once, [&r] {
-    const char* names[] = {getenv("ACCG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // ACCG_RCCL_LIB names THE library to use (no search behind it: a caller that points at a particular build must not
+    // silently get the system's instead); unset: the usual names
+    const char* forced = getenv("ACCG_RCCL_LIB");
+    const bool only_forced = forced && *forced;
+    const char* names[] = {forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
       if (!n || !*n) continue;
+      if (only_forced && n != forced) break;
       r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (r.so) break;
       r.why = dlerror();
@@ -74,6 +79,14 @@ struct accg_comm {
   uint64_t* d_buf = nullptr;     // [4] counters in, [4] counters out, [1] wall in (double), [1] wall out
   uint64_t* h_buf = nullptr;     // pinned mirror
 };
+
+// librccl can be opened and has the five entry points this file calls (no device needed): lets every rank of a job find out,
+// before any of them enters the collective ncclCommInitRank, whether all of them can.
+extern "C" int accg_comm_available(void) {
+  if (rccl()) return ACCG_OK;
+  set_error_text(("librccl not available: " + g_rccl.why).c_str());
+  return ACCG_ERR_NO_RCCL;
+}
 
 extern "C" int accg_comm_unique_id(void* id) {
   if (!id) return ACCG_ERR_BAD_ARG;

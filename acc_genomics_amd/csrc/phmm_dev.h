@@ -133,13 +133,17 @@ hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hi
 constexpr int PHMM_K8_DEFAULT = 13;   // 8 lanes per read while the rows fit K <= 13 (beyond that the 2-wave occupancy costs more than it saves)
 void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);        // reads of 1024 bases and more: (64, 16), swept in stripes
 inline bool phmm_striped(uint32_t read_len) { return read_len + 1 > 1024; }
-// x6 (fast mode only): the six-operation form of the sweep, for wavefronts all of whose reads pass phmm_x6_eligible()
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, bool x6, bool striped, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+// form (fast mode only): 7, 6 or 5 operations per cell; a wavefront runs the six- / five-operation form only if all of its reads pass
+// the form's range test (phmm_host.cpp: phmm_read_form)
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, int form, bool striped, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
 // The six-operation form keeps X divided by the row's pMX: Xs[r] = M[r-1] + c[r] Xs[r-1], c[r] = pXX[r] pMX[r-1] / pMX[r].
 // Xs is bounded by max(M) * F, F[r] = 1 + c[r] F[r-1]; M never exceeds INIT / H <= 2^120, so F <= 32 leaves a factor of 8 to
 // FLT_MAX.  Reads whose insertion qualities jump by more than ~7 dB from one base to the next push F up and stay in the
 // seven-operation form.
 constexpr float PHMM_X6_MAX_F = 32.f;
+// The five-operation form additionally keeps Y divided by the row's pMY (Ys <= max(M) / (1 - pYY)) and the diagonal term divided
+// by the consumer row's pMM: every pYY <= 31/32 and every pMM >= 1/16 keep both within a factor 32 / 16 of the unscaled values.
+constexpr float PHMM_X5_MAX_YY = 0.96875f, PHMM_X5_MIN_MM = 0.0625f;
 // fp64 rescue pass: same jobs as the fp32 pass; a wavefront redoes only the haplotypes for which one of
 // its reads came out below MIN_ACCEPTED (host_type.h:21), and exits at once when there is none.
 // strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in

@@ -212,7 +212,7 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K, lpp; bool x6, striped; uint32_t work0, n_work; int stream_cap, haps_cap; };
+struct KLaunch { int K, lpp, form; bool striped; uint32_t work0, n_work; int stream_cap, haps_cap; };   // form: 7, 6 or 5 operations per cell
 
 thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
 struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
@@ -254,7 +254,7 @@ struct accg_phmm_batch {
   std::vector<Region> regions;
   std::vector<SeqRef> rd, hp;
   std::vector<uint32_t> rd_out, hp_local, hap_ids;
-  std::vector<uint8_t> rd_x6;    // per read: eligible for the six-operation form of the fast sweep (phmm_dev.h)
+  std::vector<uint8_t> rd_form;  // per read: the cheapest form of the fast sweep it passes the range tests of: 5, 6 or 7 (phmm_dev.h)
   std::vector<PhmmWork> work;
   std::vector<KLaunch> launches;
   uint64_t pairs = 0, cells = 0, algo_bytes = 0;
@@ -273,7 +273,7 @@ struct accg_phmm_batch {
   std::vector<PhmmRegionDev> regions_dev;
   std::vector<PhmmChunkDev> chunks_dev;
   std::vector<uint32_t> sorted_reads;
-  uint32_t rescue_bound[PHMM_RESCUE_CLASSES] = {0};   // host-side upper bound of rescue jobs per class
+  uint64_t rescue_bound[PHMM_RESCUE_CLASSES] = {0};   // host-side upper bound of rescue jobs per class (64 bits: checked before narrowing)
   uint32_t rescue_off[PHMM_RESCUE_CLASSES + 1] = {0}; // class c's job array starts at rescue_off[c] (prefix sums of the bounds)
   int rescue_stream_cap = 0, rescue_haps_cap = 0;
   DevBuf<PhmmRegionDev> d_regions;
@@ -283,26 +283,34 @@ struct accg_phmm_batch {
   DevBuf<PhmmWork> d_rescue_jobs;
   DevBuf<uint32_t> d_redo;       // per rescue class (at rescue_off[c]): indices of the jobs to re-run in the strict form
   uint64_t last_kernel_ns = 0;
+  // One pass = memset + a launch per (lanes, K) class on forked streams + rescue plan + the rescue classes and their strict
+  // re-runs: captured once per arithmetic mode into a graph and replayed (every argument is fixed at batch creation).
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  bool graph_off = false;        // capture failed once, or ACCG_PHMM_GRAPH=0: plain stream launches
 };
 
 namespace {
 
 // Wire format (pairhmm/interface/PairHMMHostInterface.cpp:175-206): returns number of records, fills refs
 // with offsets relative to `base_off` (position of this blob inside the concatenated device blob).
-// PHMM_X6_MAX_F bound of phmm_dev.h on one read: _i at p + 2 len, _c at p + 4 len
-bool x6_eligible(const uint8_t* p, int len) {
+// The range tests of phmm_dev.h on one read (_i at p + 2 len, _d at p + 3 len, _c at p + 4 len): 5 = five-operation form, 6 = six, 7 = seven.
+int phmm_read_form(const uint8_t* p, int len) {
   const HostTables& t = host_tables();
-  const uint8_t *qi = p + 2 * (size_t)len, *qc = p + 4 * (size_t)len;
+  const uint8_t *qi = p + 2 * (size_t)len, *qd = p + 3 * (size_t)len, *qc = p + 4 * (size_t)len;
   double F = 1.0;
-  for (int r = 1; r < len; r++) {
+  for (int r = 1; r < len; r++) {              // PHMM_X6_MAX_F: Xs = X / pMX stays within F x max(M)
     const double c = (double)t.ph_f[qc[r] & 127] * (double)t.ph_f[qi[r - 1] & 127] / (double)t.ph_f[qi[r] & 127];
     F = 1.0 + c * F;
-    if (!(F <= (double)PHMM_X6_MAX_F)) return false;
+    if (!(F <= (double)PHMM_X6_MAX_F)) return 7;
   }
-  return true;
+  for (int r = 0; r < len; r++) {              // PHMM_X5_*: Ys = Y / pMY and the term / pMM
+    const int i = qi[r] & 127, d = qd[r] & 127, lo = i < d ? i : d, hi = i < d ? d : i;
+    if (!(t.m2m_f[((hi * (hi + 1)) >> 1) + lo] >= PHMM_X5_MIN_MM) || !(t.ph_f[qc[r] & 127] <= PHMM_X5_MAX_YY)) return 6;
+  }
+  return 5;
 }
 
-int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, std::vector<uint8_t>& x6) {
+int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, std::vector<uint8_t>& form) {
   if (bytes < 4) return ACCG_ERR_BAD_WIRE;
   int32_t n; memcpy(&n, p, 4);
   if (n < 0) return ACCG_ERR_BAD_WIRE;
@@ -315,7 +323,7 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
     if (len > ACCG_PHMM_MAX_READ) return ACCG_ERR_TOO_LONG;
     for (int k = 0; k < len; k++) if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
     refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
-    x6.push_back(x6_eligible(p + pos, len) ? 1 : 0);
+    form.push_back((uint8_t)phmm_read_form(p + pos, len));
     pos += 5 * (size_t)len;
   }
   return n;
@@ -384,9 +392,12 @@ void partition(accg_phmm_batch& b) {
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
   // read groups per region (one group = the reads of one wavefront), by descending read length so that they need the same K
-  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp; bool x6, striped; };
-  const char* e6 = getenv("ACCG_PHMM_X6");                   // A/B knob: 0 = never use the six-operation form
-  const bool allow_x6 = !(e6 && e6[0] == '0');
+  struct Group { uint32_t read[PHMM_GROUPS]; int K, lpp, form; bool striped; };
+  // A/B knobs: ACCG_PHMM_FORM=7|6|5 = the cheapest form allowed (default 5); ACCG_PHMM_X6=0 = the seven-operation form only
+  const char* e6 = getenv("ACCG_PHMM_X6");
+  const char* ef = getenv("ACCG_PHMM_FORM");
+  const int min_form = (e6 && e6[0] == '0') ? 7 : ef ? std::max(5, std::min(7, atoi(ef))) : 5;
+  auto form_of = [&](uint32_t rid) { return std::max((int)b.rd_form[rid], min_form); };
   const char* e8 = getenv("ACCG_PHMM_LPP8");                 // A/B knob: largest K run with 8 lanes per read (0 = never)
   const int max_k8 = e8 ? atoi(e8) : PHMM_K8_DEFAULT;
   std::vector<std::vector<Group>> groups(b.regions.size());
@@ -408,13 +419,14 @@ void partition(accg_phmm_batch& b) {
       // reads of at most 15 bases run in the reference's operation order even in fast mode (launch_f32), so they must not share
       // a wavefront with longer ones: a group stops at that boundary
       const bool first_tiny = b.rd[order[i]].len <= 15;
-      // ... and a wavefront runs the six-operation form only if all of its reads pass the range test: a group stops where that changes
-      const bool elig0 = b.rd_x6[order[i]] != 0;               // the group takes reads of the first one's kind
-      Q.x6 = allow_x6 && elig0 && !Q.striped;
+      // ... and a wavefront runs the six- or five-operation form only if all of its reads pass that form's range test: a group stops
+      // where the form changes (it takes reads of the first one's kind)
+      const int form0 = form_of(order[i]);
+      Q.form = Q.striped ? 7 : form0;
       uint32_t take = 0;
       for (uint32_t g = 0; g < PHMM_GROUPS; g++) {
         const bool ok = g < per && i + g < r.n_reads && take == g && (first_tiny || b.rd[order[i + g]].len > 15) &&
-                        (!allow_x6 || (b.rd_x6[order[i + g]] != 0) == elig0);
+                        form_of(order[i + g]) == form0;
         Q.read[g] = ok ? order[i + g] : PHMM_NO_READ;
         take += ok;
       }
@@ -517,7 +529,7 @@ void partition(accg_phmm_batch& b) {
     }
   }
 
-  struct Job { PhmmWork w; int K, lpp; bool x6, striped; uint64_t cost; uint32_t stream_len; };
+  struct Job { PhmmWork w; int K, lpp, form; bool striped; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (groups[ri].empty()) continue;
@@ -537,7 +549,7 @@ void partition(accg_phmm_batch& b) {
     {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
       uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
       for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
-      for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += per_class[c] * (uint32_t)runs.size();
+      for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)runs.size();
     }
     for (const Group& Q : groups[ri]) {
       PhmmWork w;
@@ -546,21 +558,21 @@ void partition(accg_phmm_batch& b) {
       for (size_t c = 0; c < runs.size(); c++) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
         const uint64_t stripes = Q.striped ? (b.rd[Q.read[0]].len + 1024) / 1024 : 1;
-        jobs.push_back({w, Q.K, Q.lpp, Q.x6, Q.striped, stripes * (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
+        jobs.push_back({w, Q.K, Q.lpp, Q.form, Q.striped, stripes * (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
       }
     }
   }
   // one launch per K; inside a launch the longest jobs go first so the tail is short
   std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
-    return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.x6 != y.x6 ? x.x6 > y.x6
+    return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.form != y.form ? x.form < y.form
                                                                                                                                 : x.cost > y.cost;
   });
   b.work.resize(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     b.work[i] = jobs[i].w;
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().x6 != jobs[i].x6 ||
+    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().form != jobs[i].form ||
         b.launches.back().striped != jobs[i].striped)
-      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].x6, jobs[i].striped, (uint32_t)i, 0, 0, 0});
+      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].form, jobs[i].striped, (uint32_t)i, 0, 0, 0});
     KLaunch& L = b.launches.back();
     L.n_work++;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
@@ -586,8 +598,9 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   return a;
 }
 
-int launch_f32(accg_phmm_batch* b, int mode) {
+int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
   ACCG_HIP(hipMemsetAsync(b->d_state.p, 0, state_words(*b) * sizeof(uint32_t), b->ctx->stream));   // flags, counts, n_rescued
+  if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
   const bool fork = b->launches.size() > 1;          // several rows-per-lane classes: run them side by side
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
@@ -607,9 +620,10 @@ int launch_f32(accg_phmm_batch* b, int mode) {
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
     // cleared: with them contracted the worst case over 1 500 random regions stays at that granularity, 2.4e-6.
     if (l.striped) a.lds_min = 0;                   // one long read per wavefront and a large LDS block: nothing to pin
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, l.x6 && !strict_l, l.striped, a, l.work0, l.n_work, st));
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, strict_l ? 7 : l.form, l.striped, a, l.work0, l.n_work, st));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
+  if (ev_end) ACCG_HIP(hipEventRecord(ev_end, b->ctx->stream));
   return ACCG_OK;
 }
 int launch_rescue(accg_phmm_batch* b, int mode) {
@@ -629,7 +643,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
   int rr = 0;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
-    const uint32_t bound = b->rescue_bound[c];
+    const uint32_t bound = (uint32_t)b->rescue_bound[c];       // < 2^32: checked at batch creation
     if (!bound) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
@@ -670,7 +684,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   for (int i = 0; i < n_regions; i++) {
     Region r;
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
-    int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd, b->rd_x6);
+    int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd, b->rd_form);
     if (nr < 0) return nr;
     int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp, b->has_n);
     if (nh < 0) return nh;
@@ -696,8 +710,8 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   hipStream_t s = ctx->stream;
   int st;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
-    if ((uint64_t)b->rescue_off[c] + b->rescue_bound[c] >= (1ull << 32)) return ACCG_ERR_TOO_LONG;
-    b->rescue_off[c + 1] = b->rescue_off[c] + b->rescue_bound[c];
+    if (b->rescue_bound[c] >= (1ull << 32) || (uint64_t)b->rescue_off[c] + b->rescue_bound[c] >= (1ull << 32)) return ACCG_ERR_TOO_LONG;
+    b->rescue_off[c + 1] = b->rescue_off[c] + (uint32_t)b->rescue_bound[c];
   }
   // One device arena: [uploaded tables and blobs][scratch][state | results].  The uploaded part is assembled in the context's
   // pinned staging and goes over in a single copy; the last words of `state` (n_rescued) sit right in front of `out`, so the
@@ -764,12 +778,49 @@ extern "C" uint64_t accg_phmm_batch_cells(const accg_phmm_batch* b) { return b ?
 extern "C" uint64_t accg_phmm_batch_algorithmic_bytes(const accg_phmm_batch* b) { return b ? b->algo_bytes : 0; }
 extern "C" uint64_t accg_phmm_batch_jobs(const accg_phmm_batch* b) { return b ? b->work.size() : 0; }
 
-extern "C" int accg_phmm_batch_run(accg_phmm_batch* b, int mode) {
-  if (!b) return ACCG_ERR_BAD_ARG;
-  ACCG_HIP(hipSetDevice(b->ctx->device));
+namespace {
+int run_direct(accg_phmm_batch* b, int mode) {
   int st = launch_f32(b, mode);
   if (st != ACCG_OK) return st;
   return launch_rescue(b, mode);
+}
+bool graphs_wanted() {
+  // Off unless ACCG_PHMM_GRAPH=1.  Measured on MI355X (tools/ab_step.py, round 3): the replayed graph is SLOWER than the plain
+  // stream launches it was captured from -- configs[1] 0.367 against 0.362 ms per step, a 128-region configs[3] shard 2.61 against
+  // 2.46 ms -- the host is far ahead of the device either way, and the graph's nodes keep the same kernel-to-kernel dependencies.
+  static const bool on = [] { const char* e = getenv("ACCG_PHMM_GRAPH"); return e && e[0] == '1'; }();
+  return on;
+}
+// The pass as a graph: the context's stream is captured (thread-local mode: other threads' HIP calls are not affected) while
+// the same launch code runs; the forked aux streams join the capture through the fork event and leave it through the join events.
+int run_graph(accg_phmm_batch* b, int mode) {
+  const int gi = mode == ACCG_PHMM_STRICT ? 1 : 0;
+  hipStream_t s = b->ctx->stream;
+  if (!b->graph_exec[gi]) {
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); b->graph_off = true; return run_direct(b, mode); }
+    const int st = run_direct(b, mode);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (st != ACCG_OK || e != hipSuccess || !g) {
+      if (g) hipGraphDestroy(g);
+      (void)hipGetLastError();
+      b->graph_off = true;
+      return st != ACCG_OK ? st : run_direct(b, mode);
+    }
+    const hipError_t ei = hipGraphInstantiate(&b->graph_exec[gi], g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ei != hipSuccess) { (void)hipGetLastError(); b->graph_exec[gi] = nullptr; b->graph_off = true; return run_direct(b, mode); }
+  }
+  ACCG_HIP(hipGraphLaunch(b->graph_exec[gi], s));
+  return ACCG_OK;
+}
+int run_pass(accg_phmm_batch* b, int mode) { return (b->graph_off || !graphs_wanted()) ? run_direct(b, mode) : run_graph(b, mode); }
+}  // namespace
+
+extern "C" int accg_phmm_batch_run(accg_phmm_batch* b, int mode) {
+  if (!b) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  return run_pass(b, mode);
 }
 
 // fp64 over every pair (FalconPairHMM::computePairhmmAVX with use_double = true, FalconPairHMM.cpp:82);
@@ -799,13 +850,11 @@ extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int
   accg_ctx* c = b->ctx;
   int st;
   for (int i = 0; i < warmup; i++) {
-    if ((st = launch_f32(b, mode)) != ACCG_OK) return st;
-    if (what == 0 && (st = launch_rescue(b, mode)) != ACCG_OK) return st;
+    if ((st = what == 0 ? run_pass(b, mode) : launch_f32(b, mode)) != ACCG_OK) return st;
   }
   ACCG_HIP(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < iters; i++) {
-    if ((st = launch_f32(b, mode)) != ACCG_OK) return st;
-    if (what == 0 && (st = launch_rescue(b, mode)) != ACCG_OK) return st;
+    if ((st = what == 0 ? run_pass(b, mode) : launch_f32(b, mode)) != ACCG_OK) return st;
   }
   ACCG_HIP(hipEventRecord(c->ev1, c->stream));
   ACCG_HIP(hipEventSynchronize(c->ev1));
@@ -814,6 +863,34 @@ extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int
   *ms_per_run = ms / iters;
   b->last_kernel_ns = (uint64_t)((double)ms / iters * 1e6);
   if (what != 0) { if ((st = launch_rescue(b, mode)) != ACCG_OK) return st; }   // leave the buffers consistent
+  return ACCG_OK;
+}
+// `iters` whole passes back to back (plain stream launches, the same kernels in the same order as accg_phmm_batch_run), each with a
+// pair of events around its fp32 sweep launches on the stream they are launched on: the dominant kernel timed INSIDE the step,
+// in the clock state the steps run in.  kernel_ms = mean time between those events (one kernel for a single-class batch, the
+// forked classes otherwise), step_ms = mean time of a whole pass.
+extern "C" int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float* kernel_ms, float* step_ms) {
+  if (!b || !kernel_ms || !step_ms || iters <= 0 || iters > 4096) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  accg_ctx* c = b->ctx;
+  std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
+  struct Drop { std::vector<hipEvent_t>& e; ~Drop() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); } } drop{ev};
+  for (hipEvent_t& e : ev) ACCG_HIP(hipEventCreate(&e));
+  int st;
+  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < iters; i++) {
+    if ((st = launch_f32(b, mode, ev[2 * i], ev[2 * i + 1])) != ACCG_OK) return st;
+    if ((st = launch_rescue(b, mode)) != ACCG_OK) return st;
+  }
+  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
+  ACCG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *step_ms = ms / iters;
+  double sum = 0;
+  for (int i = 0; i < iters; i++) { float k = 0; ACCG_HIP(hipEventElapsedTime(&k, ev[2 * i], ev[2 * i + 1])); sum += k; }
+  *kernel_ms = (float)(sum / iters);
+  b->last_kernel_ns = (uint64_t)((double)ms / iters * 1e6);
   return ACCG_OK;
 }
 extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, float* ms_per_run) {
@@ -858,6 +935,7 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
+  for (hipGraphExec_t& g : b->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   b->d_arena.release();
   delete b;
 }
@@ -888,6 +966,7 @@ extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t rea
   if (st != ACCG_OK) return st;
   const auto t1 = clk::now();
   hipEventRecord(ctx->ev0, ctx->stream);
+  b->graph_off = true;            // a single pass: capturing and instantiating a graph would cost more than it saves
   st = accg_phmm_batch_run(b, mode);
   hipEventRecord(ctx->ev1, ctx->stream);
   auto t2 = t1, t3 = t1;

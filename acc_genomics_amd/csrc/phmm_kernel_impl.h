@@ -401,13 +401,97 @@ __device__ __forceinline__ void column_rows(Rows<float, K>& s, DistRegs<K>& dq, 
   }
 }
 
+// ---- five-operation form (round 3) --------------------------------------------------------------------------------------------
+// On top of Xs = X / pMX (six-operation form) Y is kept divided by the row's pMY, Ys[c] = fma(Ys[c-1], pYY, M[c-1]) -- one operation
+// instead of two -- and the diagonal term divided by the CONSUMER row's pMM, so that M enters it with coefficient 1:
+//     T[k] = fma(Ys[k], b[k], fma(Xs[k], a[k], M[k])),   a[k] = (pMX[k] pGM[k+1]) / pMM[k+1],   b[k] = (sY[k] pGM[k+1]) / pMM[k+1]
+// (sY = pMY of a read row, 1 for a clone of row 0, whose Ys is Y = INIT/H itself); the consumer's pMM comes back through its emission
+// values: the LDS table of such a wavefront holds dist * pMM (free: it is per (base, row)).  Restates baseline_impl.cpp:84-86 /
+// avx-pairhmm-template.h:183-198; oracle model orc_phmm_forward_f32_fma5, bit-identical.  Per row: 3 VOP3 fmas, one fmac, one mul;
+// 8 K + ~23 registers (the pMY slots are not referenced and cost nothing).  Coefficient slots: pGM[k] = a[k-1], pMM[k] = b[k-1],
+// pMX[k] = chain coefficient of Xs (as in the six-operation form), pXX[k] = pYY[k]; nGM / nMM / nXX the same for row 0 of the lane
+// to the right.  Reads must pass the host's range test (phmm_read_form): the six-operation bound, every pMM >= 1/16, every pYY <= 31/32.
+#define ACCG_R5(n, xp, mp, tcin)                                  \
+  "v_fma_f32 %[t" #n "], %[X" #n "], %[gn" #n "], %[M" #n "]\n\t" \
+  "v_fma_f32 %[X" #n "], %[" xp "], %[mx" #n "], %[" mp "]\n\t"   \
+  "v_fmac_f32 %[t" #n "], %[Y" #n "], %[mn" #n "]\n\t"            \
+  "v_fma_f32 %[Y" #n "], %[Y" #n "], %[xx" #n "], %[M" #n "]\n\t" \
+  "v_mul_f32 %[M" #n "], %[d" #n "], %[" tcin "]\n\t"
+#define ACCG_R5_DPP(dpp)                             \
+  "v_fma_f32 %[t0], %[X0], %[gn0], %[M0]\n\t"        \
+  "v_fmac_f32 %[t0], %[Y0], %[mn0]\n\t"              \
+  "v_fma_f32 %[Y0], %[Y0], %[xx0], %[M0]\n\t"        \
+  "v_mov_b32_dpp %[X0], %[xo] " dpp "\n\t"           \
+  "v_mul_f32_dpp %[M0], %[ao], %[d0] " dpp "\n\t"
+#define ACCG_A5_FIRST1(dpp) ACCG_R5_DPP(dpp)
+#define ACCG_A5_FIRST2(dpp) ACCG_A5_FIRST1(dpp) ACCG_R5(1, "X0", "M0", "t0")
+#define ACCG_A5_FIRST3(dpp) ACCG_A5_FIRST2(dpp) ACCG_R5(2, "X1", "M1", "t1")
+#define ACCG_A5_FIRST4(dpp) ACCG_A5_FIRST3(dpp) ACCG_R5(3, "X2", "M2", "t2")
+#define ACCG_A5_NEXT1 ACCG_R5(0, "Xp", "Mp", "tc")
+#define ACCG_A5_NEXT2 ACCG_A5_NEXT1 ACCG_R5(1, "X0", "M0", "t0")
+#define ACCG_A5_NEXT3 ACCG_A5_NEXT2 ACCG_R5(2, "X1", "M1", "t1")
+#define ACCG_A5_NEXT4 ACCG_A5_NEXT3 ACCG_R5(3, "X2", "M2", "t2")
+#define ACCG_O5_1 [t0] "=&v"(t0), [X0] "+v"(s.X[K0]), [Y0] "+v"(s.Y[K0]), [M0] "+v"(s.M[K0])
+#define ACCG_O5_2 ACCG_O5_1, [t1] "=&v"(t1), [X1] "+v"(s.X[K0 + 1]), [Y1] "+v"(s.Y[K0 + 1]), [M1] "+v"(s.M[K0 + 1])
+#define ACCG_O5_3 ACCG_O5_2, [t2] "=&v"(t2), [X2] "+v"(s.X[K0 + 2]), [Y2] "+v"(s.Y[K0 + 2]), [M2] "+v"(s.M[K0 + 2])
+#define ACCG_O5_4 ACCG_O5_3, [t3] "=&v"(t3), [X3] "+v"(s.X[K0 + 3]), [Y3] "+v"(s.Y[K0 + 3]), [M3] "+v"(s.M[K0 + 3])
+#define ACCG_I5_1 [gn0] "v"(gn0), [mn0] "v"(mn0), [xx0] "v"(s.pXX[K0]), [d0] "v"(dq.get(K0))
+#define ACCG_I5_2 ACCG_I5_1, [gn1] "v"(gn1), [mn1] "v"(mn1), [xx1] "v"(s.pXX[K0 + 1]), [d1] "v"(dq.get(K0 + 1)), [mx1] "v"(s.pMX[K0 + 1])
+#define ACCG_I5_3 ACCG_I5_2, [gn2] "v"(gn2), [mn2] "v"(mn2), [xx2] "v"(s.pXX[K0 + 2]), [d2] "v"(dq.get(K0 + 2)), [mx2] "v"(s.pMX[K0 + 2])
+#define ACCG_I5_4 ACCG_I5_3, [gn3] "v"(gn3), [mn3] "v"(mn3), [xx3] "v"(s.pXX[K0 + 3]), [d3] "v"(dq.get(K0 + 3)), [mx3] "v"(s.pMX[K0 + 3])
+#define ACCG_I5_FIRST [xo] "v"(s.x_out), [ao] "v"(s.a_out)
+#define ACCG_I5_NEXT [mx0] "v"(s.pMX[K0]), [Xp] "v"(s.X[K0 - 1]), [Mp] "v"(s.M[K0 - 1]), [tc] "v"(tc)
+template <int LPP, int K, int Q>
+__device__ __forceinline__ void column_rows5(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj, float& tc, float& a_new) {
+  if constexpr (Q < DistRegs<K>::QT) {
+    // all rows of a quad (1 to 4 of them: the last quad of a K that is not a multiple of four is shorter) in ONE asm statement, see
+    // column_rows; waits and reloads exactly as there
+    constexpr int K0 = 4 * Q, K1 = (4 * Q + 4 < K) ? 4 * Q + 4 : K, NR = K1 - K0;
+    // what row K0 + i's Xs / Ys are multiplied with in the term it hands to the row below (the lane's last row: to the lane on the right)
+    const float gn0 = (K0 + 1 < K) ? s.pGM[(K0 + 1 < K) ? K0 + 1 : 0] : s.nGM, mn0 = (K0 + 1 < K) ? s.pMM[(K0 + 1 < K) ? K0 + 1 : 0] : s.nMM;
+    const float gn1 = (K0 + 2 < K) ? s.pGM[(K0 + 2 < K) ? K0 + 2 : 0] : s.nGM, mn1 = (K0 + 2 < K) ? s.pMM[(K0 + 2 < K) ? K0 + 2 : 0] : s.nMM;
+    const float gn2 = (K0 + 3 < K) ? s.pGM[(K0 + 3 < K) ? K0 + 3 : 0] : s.nGM, mn2 = (K0 + 3 < K) ? s.pMM[(K0 + 3 < K) ? K0 + 3 : 0] : s.nMM;
+    const float gn3 = (K0 + 4 < K) ? s.pGM[(K0 + 4 < K) ? K0 + 4 : 0] : s.nGM, mn3 = (K0 + 4 < K) ? s.pMM[(K0 + 4 < K) ? K0 + 4 : 0] : s.nMM;
+    float t0, t1, t2, t3;
+    if constexpr (Q == 0) {
+      if constexpr (LPP <= 16) {
+        if constexpr (NR == 4) asm volatile(ACCG_A5_FIRST4(ACCG_DPP_ROW) : ACCG_O5_4 : ACCG_I5_4, ACCG_I5_FIRST);
+        else if constexpr (NR == 3) asm volatile(ACCG_A5_FIRST3(ACCG_DPP_ROW) : ACCG_O5_3 : ACCG_I5_3, ACCG_I5_FIRST);
+        else if constexpr (NR == 2) asm volatile(ACCG_A5_FIRST2(ACCG_DPP_ROW) : ACCG_O5_2 : ACCG_I5_2, ACCG_I5_FIRST);
+        else asm volatile(ACCG_A5_FIRST1(ACCG_DPP_ROW) : ACCG_O5_1 : ACCG_I5_1, ACCG_I5_FIRST);
+      } else {
+        if constexpr (NR == 4) asm volatile(ACCG_A5_FIRST4(ACCG_DPP_WAVE) : ACCG_O5_4 : ACCG_I5_4, ACCG_I5_FIRST);
+        else if constexpr (NR == 3) asm volatile(ACCG_A5_FIRST3(ACCG_DPP_WAVE) : ACCG_O5_3 : ACCG_I5_3, ACCG_I5_FIRST);
+        else if constexpr (NR == 2) asm volatile(ACCG_A5_FIRST2(ACCG_DPP_WAVE) : ACCG_O5_2 : ACCG_I5_2, ACCG_I5_FIRST);
+        else asm volatile(ACCG_A5_FIRST1(ACCG_DPP_WAVE) : ACCG_O5_1 : ACCG_I5_1, ACCG_I5_FIRST);
+      }
+    } else {
+      if constexpr (NR == 4) asm volatile(ACCG_A5_NEXT4 : ACCG_O5_4 : ACCG_I5_4, ACCG_I5_NEXT);
+      else if constexpr (NR == 3) asm volatile(ACCG_A5_NEXT3 : ACCG_O5_3 : ACCG_I5_3, ACCG_I5_NEXT);
+      else if constexpr (NR == 2) asm volatile(ACCG_A5_NEXT2 : ACCG_O5_2 : ACCG_I5_2, ACCG_I5_NEXT);
+      else asm volatile(ACCG_A5_NEXT1 : ACCG_O5_1 : ACCG_I5_1, ACCG_I5_NEXT);
+    }
+    const float tl = NR == 4 ? t3 : NR == 3 ? t2 : NR == 2 ? t1 : t0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)gn1; (void)gn2; (void)gn3; (void)mn1; (void)mn2; (void)mn3;
+    if (K1 < K) tc = tl; else a_new = tl;
+    if constexpr (Q + 1 < DistRegs<K>::QT) lgkm_wait_visible<DistRegs<K>::QT - 1>();
+    dq.template load<Q>(addr_next, tail_adj);          // the same registers, for the next step
+    column_rows5<LPP, K, Q + 1>(s, dq, addr_next, tail_adj, tc, a_new);
+  }
+}
+#undef ACCG_R5
+#undef ACCG_R5_DPP
+
 // One column for every lane; returns what the group's last lane adds to its running sum of the last read row.
-template <int LPP, int K, bool X6>
+// XF: 0 = seven-operation form, 6 = six-operation form, 5 = five-operation form.
+template <int LPP, int K, int XF>
 __device__ __forceinline__ float column_f32_asm(Rows<float, K>& s, DistRegs<K>& dq, unsigned addr_next, unsigned tail_adj) {
   float tc = 0.f, a_new = 0.f;
-  column_rows<LPP, K, X6, 0>(s, dq, addr_next, tail_adj, tc, a_new);
+  constexpr bool X6 = XF == 6, X5 = XF == 5;
+  if constexpr (X5) column_rows5<LPP, K, 0>(s, dq, addr_next, tail_adj, tc, a_new);
+  else column_rows<LPP, K, X6, 0>(s, dq, addr_next, tail_adj, tc, a_new);
   s.a_out = a_new;
-  if (X6) {
+  if (X6 || X5) {
     // Xs of row 0 of the lane to the right: the same single fma as inside a lane (nMX is 1, or 0 towards another read's lanes and
     // in a group's last lane: the product with it is exact); the last read row's M + X = M + pMX * Xs likewise
     // (nMX is 1 in every lane but a group's last, whose hand-off nobody needs: what it passes to the first lane of the next read --
@@ -500,11 +584,11 @@ __device__ __forceinline__ double column_f64_asm(Rows<double, K>& s, DistRegsD<K
 template <typename T, int K> struct AsmCol;
 template <int K> struct AsmCol<float, K> {
   typedef DistRegs<K> Regs;
-  template <int LPP, bool X6> static __device__ __forceinline__ float column(Rows<float, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f32_asm<LPP, K, X6>(s, dq, a, t); }
+  template <int LPP, int XF> static __device__ __forceinline__ float column(Rows<float, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f32_asm<LPP, K, XF>(s, dq, a, t); }
 };
 template <int K> struct AsmCol<double, K> {
   typedef DistRegsD<K> Regs;
-  template <int LPP, bool X6> static __device__ __forceinline__ double column(Rows<double, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f64_asm<LPP, K>(s, dq, a, t); }
+  template <int LPP, int XF> static __device__ __forceinline__ double column(Rows<double, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f64_asm<LPP, K>(s, dq, a, t); }
 };
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
@@ -518,9 +602,10 @@ static __global__ void phmm_timing_print() {
   for (int i = 0; i < 8; i++) g_phmm_t[i] = 0;
 }
 #endif
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false, bool STRIPED = false>
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool X6 = XF == 6, X5 = XF == 5;     // six- / five-operation form of the fp32 fast sweep (0: seven operations)
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT, K) && !STRIPED;
   constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
@@ -667,6 +752,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         s.pMM[k] = real ? tMM[k] : T(0); s.pGM[k] = real ? tGM[k] : T(0); s.pMX[k] = real ? tMX[k] : T(0);
         s.pXX[k] = real ? tXX[k] : T(1); s.pMY[k] = real ? tMY[k] : T(0);
         dM[e] = real ? tdM[k] : T(0); dX[e] = real ? tdX[k] : T(0);
+        if constexpr (X5) { dM[e] = dM[e] * s.pMM[k]; dX[e] = dX[e] * s.pMM[k]; }   // five-operation form: the row's pMM rides on its emission values
         rbase[e] = real ? char_index((uint8_t)vb[k]) : CH_A;
       }
     }
@@ -699,7 +785,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     else if (l == LPP - 1 && LPP != 32 && LPP != 8) { s.nMM = T(0); s.nGM = T(0); s.nMX = T(1); s.nXX = T(1); }
     else { s.nMM = T(0); s.nGM = T(0); s.nMX = T(0); s.nXX = T(0); }
   }
-  if (!STRICT) {
+  if (!STRICT && !X5) {
 #pragma unroll
     for (int k = 0; k < K; k++) s.pMY[k] = s.pMY[k] * (k + 1 < K ? s.pGM[k + 1] : s.nGM);
   }
@@ -725,6 +811,28 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
     for (int k = K - 1; k >= 1; k--) {
       s.pGM[k] = s.pGM[k] * s.pMX[k - 1];
+      s.pMX[k] = s.pMX[k] != T(0) ? (s.pXX[k] * s.pMX[k - 1]) / s.pMX[k] : T(0);
+    }
+  }
+  if constexpr (X5) {
+    // Five-operation form (see column_rows5).  From here on: pGM[k] = a[k-1], pMM[k] = b[k-1] (what the term row k-1 hands down
+    // multiplies its Xs / Ys with), pMX[k] = the chain coefficient of Xs, nGM / nMM / nXX the same three for row 0 of the lane to the
+    // right; a consumer with pMM = 0 is a clone of row 0 (an eligible read has none, phmm_read_form) or nobody: coefficients 0.
+    s.xl = s.pMX[K - 1];
+    {
+      const T sY = (K - 1 < s.npad) ? T(1) : s.pMY[K - 1];
+      const T g = s.nGM, m = s.nMM, nmx_true = s.nMX;
+      s.nGM = m != T(0) ? (s.xl * g) / m : T(0);
+      s.nMM = m != T(0) ? (sY * g) / m : T(0);
+      if (l == LPP - 1) { s.nXX = T(0); s.nMX = T(0); }
+      else { s.nXX = nmx_true != T(0) ? (s.nXX * s.xl) / nmx_true : T(0); s.nMX = T(1); }
+    }
+#pragma unroll
+    for (int k = K - 1; k >= 1; k--) {
+      const T sY = (k - 1 < s.npad) ? T(1) : s.pMY[k - 1];
+      const T g = s.pGM[k], m = s.pMM[k];
+      s.pGM[k] = m != T(0) ? (s.pMX[k - 1] * g) / m : T(0);
+      s.pMM[k] = m != T(0) ? (sY * g) / m : T(0);
       s.pMX[k] = s.pMX[k] != T(0) ? (s.pXX[k] * s.pMX[k - 1]) / s.pMX[k] : T(0);
     }
   }
@@ -784,7 +892,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_cmp_eq_u32 vcc, %3, %1\n\ts_or_b32 %0, vcc_lo, vcc_hi" : "=s"(any_next) : "v"(o1n), "n"(NLD - 1), "s"(nchar_s) : "vcc", "scc");
         asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a));
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
-        const T contrib = AsmCol<T, K>::template column<LPP, X6>(s, dq, addr_next, tail_adj);
+        const T contrib = AsmCol<T, K>::template column<LPP, XF>(s, dq, addr_next, tail_adj);
         const T acc_done = s.acc;            // the running sum up to the step before: what a bubble lane reports
         s.acc = s.acc + contrib;             // (added before the branch: a bubble lane overwrites the sum, there is no second value of contrib to merge)
         if (__builtin_expect(any_b != 0, 0)) {
@@ -810,7 +918,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
             for (int k = 0; k < K; k++) {
               s.M[k] = T(0); s.X[k] = T(0);
-              s.Y[k] = (k < s.npad) ? y0 * (X6 ? s.gclone : (k + 1 < K ? s.pGM[k + 1] : s.nGM)) : T(0);
+              // (five-operation form: a clone's Ys is INIT/H itself; else Y rides pre-multiplied by the consumer row's pGM)
+              s.Y[k] = (k < s.npad) ? (X5 ? y0 : y0 * (X6 ? s.gclone : (k + 1 < K ? s.pGM[k + 1] : s.nGM))) : T(0);
             }
             s.x_out = T(0);
             s.acc = T(0);
@@ -890,16 +999,18 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   return __any(tiny);
 }
 
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE, bool X6 = false, bool STRIPED = false>
-__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base) {
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false>
+__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, uint32_t n_work) {
   if (RESCUE && a.job_count) {
     // the number of jobs is only known on the device (phmm_rescue_plan); the grid is capped on the host and every wavefront
     // walks the job array with the grid's stride, so a class with nothing to do costs a few hundred empty wavefronts instead
     // of one per potential job
-    const uint32_t n = __builtin_amdgcn_readfirstlane(*a.job_count);
+    // (never beyond the class's slots: the planner counts the jobs it had to drop too, phmm_rescue_plan)
+    const uint32_t n_dev = __builtin_amdgcn_readfirstlane(*a.job_count);
+    const uint32_t n = n_dev < n_work ? n_dev : n_work;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
       const uint32_t job = a.job_map ? a.job_map[i] : i;
-      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, job, !a.is_redo);
+      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED>(a, work_base, job, !a.is_redo);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next job rebuilds the LDS tables this one still read
       __builtin_amdgcn_wave_barrier();
       // The contracted column is within 1e-8 of the reference's order as long as the result stays clear of the denormal range;
@@ -909,27 +1020,27 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
       if (!STRICT && tiny && a.redo_count && threadIdx.x == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = job;
     }
   } else {
-    phmm_job<T, K, LPP, STRICT, RESCUE, X6, STRIPED>(a, work_base, blockIdx.x);
+    phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED>(a, work_base, blockIdx.x);
   }
 }
 
-template <typename T, bool STRICT, bool RESCUE, bool X6 = false>
+template <typename T, bool STRICT, bool RESCUE, int XF = 0>
 hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st, bool striped = false,
                   uint32_t grid_cap = PHMM_RESCUE_GRID) {
   if (n_work == 0) return hipSuccess;
   dim3 grid(RESCUE && a.job_count ? (n_work < grid_cap ? n_work : grid_cap) : n_work), block(64);
   if (striped) {      // reads of 1024 bases and more: 64 lanes x 16 rows per stripe, the generic column
-    if (K != 16 || lpp != 64 || X6) return hipErrorInvalidValue;
+    if (K != 16 || lpp != 64 || XF != 0) return hipErrorInvalidValue;
     size_t lds = phmm_lds_bytes(16, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, 64, false, true);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((phmm_kernel<T, 16, 64, STRICT, RESCUE, false, true>), grid, block, lds, st, a, work_base);
+    hipLaunchKernelGGL((phmm_kernel<T, 16, 64, STRICT, RESCUE, 0, true>), grid, block, lds, st, a, work_base, n_work);
     return hipGetLastError();
   }
 #define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
     size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT, KK)); \
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;                                                     \
-    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE, X6>), grid, block, lds, st, a, work_base);         \
+    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE, XF>), grid, block, lds, st, a, work_base, n_work); \
   } break;
 #ifdef ACCG_PHMM_DEV_SUBSET      // development builds: only the configs[1] kernels (seconds instead of minutes to compile)
   if (lpp == 8 && K == 13) {

@@ -68,13 +68,27 @@ def region_cost(reads_ser, haps_ser):
 
 # ---- communicators -----------------------------------------------------------------------------------------
 
+def _launcher_token():
+    """Start time (clock ticks since boot, /proc/<pid>/stat field 22) of the launcher = this process's parent: together with its
+    pid a per-run nonce that every rank of one launcher computes alike and that no earlier run can have had."""
+    try:
+        st = open("/proc/%d/stat" % os.getppid()).read()
+        return st[st.rindex(")") + 2:].split()[19]
+    except (OSError, ValueError, IndexError):
+        return "0"
+
+
 def comm_file_default():
     """Where rank 0 leaves the RCCL unique id for the other ranks of this node: ACCG_COMM_FILE when the launcher set it
-    (bench.py's own spawner does), else a name all workers of one torch.distributed.run agent agree on."""
+    (bench.py's own spawner does: a fresh mkdtemp), else a name all workers of one torch.distributed.run agent agree on --
+    port, the agent's pid and start time, and the elastic run id when there is one -- so a file left behind by a run that died
+    is never taken for this run's."""
     p = os.environ.get("ACCG_COMM_FILE")
     if p:
         return p
-    return "/tmp/accg_comm_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    rid = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    rid = "_" + "".join(ch for ch in rid if ch.isalnum())[:32] if rid and rid != "none" else ""
+    return "/tmp/accg_comm_%s_%d_%s%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), _launcher_token(), rid)
 
 
 def _wait_for(path, timeout):
@@ -83,6 +97,48 @@ def _wait_for(path, timeout):
         if time.time() - t0 > timeout:
             raise TimeoutError("rank file %s did not appear within %.0f s" % (path, timeout))
         time.sleep(0.01)
+
+
+def exchange_status(base, phase, rank, world, ok, reason="", timeout=120.0):
+    """Every rank publishes (ok, reason) for `phase` next to the rendezvous file and reads everybody's: the ranks decide TOGETHER
+    whether the RCCL communicator is used, so that no rank sits in a collective the others have given up on.
+    Returns [(ok, reason)] by rank; a rank that does not report within `timeout` counts as failed."""
+    mine = "%s.%s.%d" % (base, phase, rank)
+    with open(mine + ".tmp", "w") as f:
+        json.dump([bool(ok), str(reason)], f)
+    os.replace(mine + ".tmp", mine)
+    out = []
+    for r in range(world):
+        p = "%s.%s.%d" % (base, phase, r)
+        try:
+            _wait_for(p, timeout)
+            v = json.load(open(p))
+            out.append((bool(v[0]), v[1]))
+        except (TimeoutError, OSError, ValueError) as e:
+            out.append((False, "rank %d did not report (%s)" % (r, e)))
+    return out
+
+
+def _forget_status(base, rank):
+    for phase in ("pre", "init"):
+        try:
+            os.unlink("%s.%s.%d" % (base, phase, rank))
+        except OSError:
+            pass
+
+
+def rccl_preflight(rank, world, base=None):
+    """Can EVERY rank load librccl?  Needs no GPU (accg_comm_available only opens the library), so it runs before the contexts
+    exist and before any rank enters the collective ncclCommInitRank.  -> (all_ok, reason of the first rank that cannot)."""
+    if world <= 1:
+        return True, ""
+    from .lib import load
+    L = load()
+    ok = L.accg_comm_available() == 0
+    why = "" if ok else L.accg_last_hip_error().decode()
+    res = exchange_status(base or comm_file_default(), "pre", rank, world, ok, why)
+    bad = [(r, w) for r, (o, w) in enumerate(res) if not o]
+    return (not bad), ("" if not bad else "rank %d: %s" % bad[0])
 
 
 class RcclComm:
@@ -131,6 +187,9 @@ class RcclComm:
         if self.h:
             self.L.accg_comm_destroy(self.h)
             self.h = C.c_void_p()
+        if getattr(self, "_status_base", None):     # every rank has read everybody's status long ago (barriers since)
+            _forget_status(self._status_base, self.rank)
+            self._status_base = None
 
 
 class FileComm:
@@ -142,6 +201,20 @@ class FileComm:
     def __init__(self, ctx, rank, world, directory, timeout=600.0):
         self.ctx, self.rank, self.world, self.dir, self.timeout, self.seq = ctx, rank, world, directory, timeout, 0
         os.makedirs(directory, exist_ok=True)
+        # a directory somebody used before (same name, e.g. a fixed ACCG_COMM_FILE): rank 0 removes what is left in it and
+        # says so through a `ready` file carrying this launcher's token; nobody reads a counter file before having seen it
+        token = "%d_%s" % (os.getppid(), _launcher_token())        # the ranks of one job are children of one launcher
+        ready = os.path.join(directory, "ready_%s" % token)
+        if rank == 0:
+            for f in os.listdir(directory):
+                if f.startswith("ar_") or (f.startswith("ready_") and f != os.path.basename(ready)):
+                    try:
+                        os.unlink(os.path.join(directory, f))
+                    except OSError:
+                        pass
+            open(ready, "w").close()
+        else:
+            _wait_for(ready, timeout)
 
     def allreduce(self, cells, pairs, kernel_ns, rescued, wall_s):
         if self.ctx is not None:
@@ -164,29 +237,60 @@ class FileComm:
         self.allreduce(0, 0, 0, 0, 0.0)
 
     def close(self):
-        pass
+        if self.seq:                      # everybody has read file seq-1 of every rank before writing its seq-th: safe to drop
+            for q in range(1, self.seq):
+                try:
+                    os.unlink(os.path.join(self.dir, "ar_%d_%d.json" % (q, self.rank)))
+                except OSError:
+                    pass
 
 
-def open_comm(ctx, rank, world, backend=None, allow_fallback=False):
+class CommError(RuntimeError):
+    pass
+
+
+def open_comm(ctx, rank, world, backend=None, allow_fallback=False, preflight=None):
     """backend: "rccl" (default) or "file" (ACCG_COMM_BACKEND=file, directory = ACCG_COMM_FILE + ".d").
 
-    allow_fallback (bench.py only): if the RCCL communicator cannot be brought up (librccl missing, bootstrap refused), say so
-    loudly on stderr and reduce the counters through the file double instead, so that a multi-GPU run still yields its numbers;
-    the returned object's `backend` / `fallback_reason` tell which one ran.  The compute path is not involved either way."""
+    With more than one rank the RCCL communicator is a COLLECTIVE decision: every rank first reports whether it can load
+    librccl (rccl_preflight; pass its result as `preflight` when it already ran), only then do they enter ncclCommInitRank, and
+    afterwards they report how that went.  Unless all ranks succeeded, all of them raise CommError naming RCCL -- or, with
+    allow_fallback (bench.py --allow-comm-fallback, rehearsals only), all of them together reduce the counters through the file
+    double instead; the returned object's `backend` / `fallback_reason` say which one ran.  The compute path is not involved."""
     backend = backend or os.environ.get("ACCG_COMM_BACKEND", "rccl")
+    base = comm_file_default()
     if backend == "file":
-        return FileComm(ctx, rank, world, comm_file_default() + ".d")
-    try:
+        return FileComm(ctx, rank, world, base + ".d")
+    if world <= 1:
         return RcclComm(ctx, rank, world)
-    except Exception as e:                      # AccgError (ACCG_ERR_RCCL / ACCG_ERR_NO_RCCL), TimeoutError on the id file
-        if not allow_fallback or world == 1:
-            raise
+
+    def give_up(reason):
+        if not allow_fallback:
+            raise CommError("RCCL communicator over %d ranks could not be brought up (%s); the multi-GPU counters need RCCL "
+                            "(bench.py --allow-comm-fallback reduces them through files instead)" % (world, reason))
         import sys
-        print("acc_genomics_amd.dist: rank %d: RCCL communicator failed (%s); counters go through files in %s.d instead"
-              % (rank, e, comm_file_default()), file=sys.stderr)
-        c = FileComm(ctx, rank, world, comm_file_default() + ".d")
-        c.fallback_reason = str(e)
+        print("acc_genomics_amd.dist: rank %d: RCCL communicator failed (%s); ALL ranks reduce the counters through files in %s.d instead"
+              % (rank, reason, base), file=sys.stderr)
+        c = FileComm(ctx, rank, world, base + ".d")
+        c.fallback_reason = reason
         return c
+
+    ok, why = preflight if preflight is not None else rccl_preflight(rank, world, base)
+    if not ok:
+        return give_up(why)
+    comm, err = None, ""
+    try:
+        comm = RcclComm(ctx, rank, world)
+    except Exception as e:                      # AccgError (ACCG_ERR_RCCL / ACCG_ERR_NO_RCCL), TimeoutError on the id file
+        err = "%s: %s" % (type(e).__name__, e)
+    res = exchange_status(base, "init", rank, world, comm is not None and comm.uses_rccl, err)
+    bad = [(r, w) for r, (o, w) in enumerate(res) if not o]
+    if not bad:
+        comm._status_base = base
+        return comm
+    if comm is not None:
+        comm.close()
+    return give_up("rank %d: %s" % bad[0])
 
 
 def gather_per_rank(comm, cells, pairs, kernel_ns, rescued, wall_s):
@@ -222,9 +326,12 @@ def run_sharded_phmm(ctx, comm, serialized_regions, costs, steps, warmup, mode=0
     comm.barrier()
     _, _, cnt = batch.results(want_log10=False)
     k_ms = batch.time(mode, warmup=0, iters=max(1, min(steps, 5)))
-    cells, pairs, kns, resc, wmax = comm.allreduce(batch.cells * steps, batch.pairs * steps, int(k_ms * 1e6), int(cnt.rescued), wall)
-    per_rank = gather_per_rank(comm, batch.cells, b - a, int(k_ms * 1e6), int(cnt.rescued), wall)
+    # the reduced vector is in ONE unit throughout: totals over the `steps` timed passes (cells / kernel_ns is then the
+    # device-time GCUPS the reference prints, FalconPairHMM.cpp:1214-1220); kernel_ns = mean pass on the launch stream x steps
+    cells, pairs, kns, resc, wmax = comm.allreduce(batch.cells * steps, batch.pairs * steps, int(k_ms * 1e6) * steps,
+                                                   int(cnt.rescued) * steps, wall)
+    per_rank = gather_per_rank(comm, batch.cells, b - a, int(k_ms * 1e6), int(cnt.rescued), wall)     # per pass
     for r in per_rank:
         r["regions"] = r.pop("pairs")
-    totals = {"cells": cells, "pairs": pairs, "kernel_ns_sum": kns, "rescued": resc, "wall_s": wmax}
+    totals = {"steps": steps, "cells": cells, "pairs": pairs, "kernel_ns": kns, "rescued": resc, "wall_s": wmax}
     return batch, (a, b), totals, per_rank

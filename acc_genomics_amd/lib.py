@@ -56,12 +56,15 @@ def load():
     L.accg_phmm_batch_results_f64.argtypes = [vp, vp]
     L.accg_phmm_batch_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_phmm_batch_time2.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.accg_phmm_batch_time_in_step.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.accg_ctx_clock_ghz.argtypes = [vp, C.POINTER(C.c_float)]
     L.accg_phmm_batch_results.argtypes = [vp, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_batch_destroy.argtypes = [vp]
     L.accg_counters_pack.argtypes = [C.POINTER(Counters), C.POINTER(C.c_uint64)]
     L.accg_ctx_synchronize.argtypes = [vp]
     L.accg_ctx_trim.argtypes = [vp]
     L.accg_comm_unique_id.argtypes = [vp]
+    L.accg_comm_available.argtypes = []
     L.accg_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     for n in ("accg_comm_rank", "accg_comm_world", "accg_comm_uses_rccl", "accg_comm_barrier"):
         getattr(L, n).argtypes = [vp]
@@ -135,6 +138,12 @@ class Context:
         """accg_ctx_synchronize: everything queued on the context's stream has finished."""
         _check(self.L.accg_ctx_synchronize(self.h))
 
+    def clock_ghz(self):
+        """accg_ctx_clock_ghz: the shader clock held under load right now."""
+        g = C.c_float()
+        _check(self.L.accg_ctx_clock_ghz(self.h, C.byref(g)))
+        return g.value
+
     @property
     def name(self):
         buf = C.create_string_buffer(160)
@@ -189,6 +198,12 @@ class PhmmBatch:
         ms = C.c_float()
         _check(self.L.accg_phmm_batch_time2(self.h, mode, 1 if fp32_pass_only else 0, warmup, iters, C.byref(ms)))
         return ms.value
+
+    def time_in_step(self, mode=ACCG_PHMM_FAST, iters=20):
+        """(kernel_ms, step_ms): the fp32 sweep timed with HIP events inside `iters` whole back-to-back passes, and the pass itself."""
+        k, s = C.c_float(), C.c_float()
+        _check(self.L.accg_phmm_batch_time_in_step(self.h, mode, iters, C.byref(k), C.byref(s)))
+        return k.value, s.value
 
     def results(self, want_log10=True):
         raw = np.zeros(self.pairs, np.float32)

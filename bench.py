@@ -22,6 +22,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import sys
 import subprocess
 import tempfile
@@ -46,6 +47,18 @@ def traffic():
     """profiles/traffic.json: per-launch HBM bytes and instruction counts from the rocprofv3 --pmc passes (tools/prof_pmc.sh)."""
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     return json.load(open(tr)) if os.path.exists(tr) else {}
+
+
+def pmc_source():
+    """Where the counter-derived fields of a line come from: they are NOT measured by this run (a bench run carries no profiler);
+    bench.py copies them from profiles/traffic.json, which tools/make_traffic.py writes from the builder's rocprofv3 --pmc passes."""
+    import hashlib
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tr):
+        return None
+    j = json.load(open(tr))
+    return "profiles/traffic.json sha256:%s (%s); copied, not measured in this run" % (
+        hashlib.sha256(open(tr, "rb").read()).hexdigest()[:12], j.get("source", "builder-side rocprofv3 --pmc passes, tools/prof_pmc.sh"))
 
 
 def valu_issue(insts_per_launch, k_ms, ubench_ns=None, waves_per_simd=None):
@@ -82,43 +95,51 @@ def host_cores():
     return n
 
 
-def cpu_baseline_phmm(reads, haps, min_wall=1.0):
+def cpu_baseline_phmm(reads, haps):
     """The reference's own AVX path (compute_fp_avxs + fp64 rescue + log10, FalconPairHMM.cpp:69-95), compiled
-    in place into oracle/_ref, on all host cores: the pair loop is split over threads by read."""
+    in place into oracle/_ref, on all host cores (the pair loop split over threads by read) and on one core.
+    SURVEY.md 8d protocol: wall time around the pair loop only, first run discarded, median of 5."""
     import orc
     if not orc.ref_available():
         return None
     R = orc.ref_phmm()
-    n_threads = host_cores()
-    slices = np.array_split(np.arange(len(reads)), n_threads)
     hl = np.array([len(h) for h in haps], np.int32)
     hk = orc.cstrs(list(haps))
 
-    def work(idx, out):
+    def prep(idx):
         rs = [reads[i] for i in idx]
         rl = np.array([len(r["b"]) for r in rs], np.int32)
         keep = [orc.cstrs([r[k] for r in rs]) for k in ("b", "q", "i", "d", "c")]
-        l10 = np.zeros(len(rs) * len(haps), np.float64)
-        R.ref_phmm_region(1, len(rs), orc.ptr(rl, orc.i32p), *keep, len(haps), orc.ptr(hl, orc.i32p), hk, None,
-                          orc.ptr(l10, orc.f64p))
-        out.append(l10)
+        return rs, rl, keep, np.zeros(len(rs) * len(haps), np.float64)
 
-    cells_once = sum(len(r["b"]) for r in reads) * int(hl.sum())
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        outs, th = [], []
-        for s in slices:
-            if len(s):
-                t = threading.Thread(target=work, args=(s, outs)); t.start(); th.append(t)
-        for t in th:
-            t.join()
-        reps += 1
-        wall = time.perf_counter() - t0
-        if wall >= min_wall:
-            break
-    return {"value": cells_once * reps / wall / 1e9, "unit": "GCUPS", "cores": n_threads, "kind": "reference",
-            "sample": "%d x the full configs[1] batch (2048 reads x 32 haps, 101x300) through compute_fp_avxs + rescue + log10, "
-                      "%.2f s wall" % (reps, wall)}
+    def work(job):
+        rs, rl, keep, l10 = job
+        R.ref_phmm_region(1, len(rs), orc.ptr(rl, orc.i32p), *keep, len(haps), orc.ptr(hl, orc.i32p), hk, None, orc.ptr(l10, orc.f64p))
+
+    def median_rate(jobs, cells):
+        ts = []
+        for rep in range(6):                       # first one discarded
+            th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            ts.append(time.perf_counter() - t0)
+        return cells / float(np.median(ts[1:])) / 1e9, float(np.median(ts[1:]))
+
+    n_threads = host_cores()
+    jobs = [prep(s) for s in np.array_split(np.arange(len(reads)), n_threads) if len(s)]
+    cells_all = sum(len(r["b"]) for r in reads) * int(hl.sum())
+    v_all, t_all = median_rate(jobs, cells_all)
+    n1 = min(len(reads), 128)
+    cells_1 = sum(len(r["b"]) for r in reads[:n1]) * int(hl.sum())
+    v_one, t_one = median_rate([prep(np.arange(n1))], cells_1)
+    return {"value": v_all, "unit": "GCUPS", "cores": n_threads, "kind": "reference",
+            "single_core": {"value": v_one, "unit": "GCUPS", "cores": 1,
+                            "sample": "%d reads x %d haps of the same batch, median of 5 runs of %.3f s" % (n1, len(haps), t_one)},
+            "sample": "the full configs[1] batch (2048 reads x 32 haps, 101x300) through compute_fp_avxs + rescue + log10, "
+                      "median of 5 runs of %.3f s (first run discarded)" % t_all}
 
 
 def make_c2(rank, n=1 << 20):
@@ -434,7 +455,9 @@ def bench_c3(ctx, comm, steps, warmup, mode, with_cpu):
                                       "lengths per region) = 2097152 pairs in all, 1 % N, 10 % unrelated reads; fp32 sweep + fp64 rescue; "
                                       "regions cut over the ranks by cell count (shard_by_cost)",
                           "regions": C3_REGIONS, "pairs": tot["pairs"] // steps, "cells": tot["cells"] // steps},
-               "rescued": tot["rescued"], "rescued_frac": tot["rescued"] / max(1, tot["pairs"] // steps),
+               "rescued": tot["rescued"] // steps, "rescued_frac": tot["rescued"] / max(1, tot["pairs"]),
+               "counters": {"cells": tot["cells"], "pairs": tot["pairs"], "kernel_ns": tot["kernel_ns"], "rescued": tot["rescued"],
+                            "unit": "totals over the %d timed passes and all ranks" % steps},
                "per_rank": [{"rank": r["rank"], "regions": r["regions"], "cells": r["cells"], "kernel_ms": r["kernel_ns"] / 1e6,
                              "ms_per_step": r["wall_s"] / steps * 1e3, "rescued": r["rescued"]} for r in per_rank],
                "setup_s": time.perf_counter() - t_gen - wall}
@@ -461,6 +484,39 @@ def bench_c3(ctx, comm, steps, warmup, mode, with_cpu):
     return out
 
 
+def bench_e2e(ctx, reads, haps, n_c3, mode):
+    """PCIe-inclusive rates (SURVEY.md 8d "H2D + kernel + D2H end to end"; the reference's phases FalconPairHMM.cpp:1049-1162, printed
+    :1214-1220): wire blobs in pageable host memory in, log10 likelihoods in host memory out, through accg_phmm_region -- the call
+    compute_fpga / FalconPairHMM::computePairhmm make once per active region.  Never the headline `value`."""
+    from acc_genomics_amd import synth
+    rs, hs = synth.serialize_reads(reads), synth.serialize_haps(haps)
+    n = len(reads) * len(haps)
+    cells = sum(len(r["b"]) for r in reads) * sum(len(h) for h in haps)
+    ts = []
+    for rep in range(6):
+        t0 = time.perf_counter()
+        ctx.phmm_region(rs, hs, n, mode)
+        ts.append(time.perf_counter() - t0)
+    t1 = float(np.median(ts[1:]))
+    out = {"c1": {"ms_per_call": t1 * 1e3, "value": cells / t1 / 1e9, "unit": "GCUPS",
+                  "what": "one configs[1] region (2048 x 32) per call, median of 5 calls"}}
+    if n_c3 > 0:
+        regs = [c3_region(k) for k in range(n_c3)]
+        ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
+        c3_cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs)
+        ts = []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            for a, b, m in ser:
+                ctx.phmm_region(a, b, m, mode)
+            ts.append(time.perf_counter() - t0)
+        t3 = float(np.median(ts[1:]))
+        out["c3_slice"] = {"regions": n_c3, "ms_total": t3 * 1e3, "ms_per_region": t3 / n_c3 * 1e3, "value": c3_cells / t3 / 1e9, "unit": "GCUPS",
+                           "what": "the first %d configs[3] regions (128 reads x 16 haplotypes each), one blocking call per region, median of 3 passes" % n_c3}
+    out["note"] = "host memory to host memory, parse + job sizing + upload + kernels + download + log10 all inside; not the headline value"
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: this process (which has not touched a GPU and will not) starts the N
     ranks as children, hands them a fresh rendezvous file for the RCCL unique id, relays rank 0's JSON line and returns the
@@ -471,10 +527,11 @@ def spawn_ranks(n, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_PORT", "29512")
     procs = []
+    out0 = open(os.path.join(d, "rank0.stdout"), "w+b")      # a file, not a pipe: the line outgrows a pipe buffer nobody drains
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
         live = set(range(n))
@@ -490,22 +547,15 @@ def spawn_ranks(n, argv):
                     for q in live:
                         procs[q].terminate()
             time.sleep(0.05)
-        out = procs[0].stdout.read().decode()
         if rc == 0:
-            sys.stdout.write(out)
+            out0.seek(0)
+            sys.stdout.write(out0.read().decode())
     finally:
         for q in procs:
             if q.poll() is None:
                 q.kill()
-        for f in os.listdir(d):
-            try:
-                os.unlink(os.path.join(d, f))
-            except OSError:
-                pass
-        try:
-            os.rmdir(d)
-        except OSError:
-            pass
+        out0.close()
+        shutil.rmtree(d, ignore_errors=True)
     return rc
 
 
@@ -516,6 +566,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-comm-fallback", action="store_true",
+                    help="N > 1 rehearsals only: if RCCL cannot be brought up on every rank, reduce the counters through files instead of failing")
+    ap.add_argument("--e2e-regions", type=int, default=64, help="configs[3] regions of the host-to-host (PCIe-inclusive) leg (0 = skip it)")
     ap.add_argument("--c3-steps", type=int, default=20, help="passes over the sharded configs[3] batch (0 = skip that leg)")
     ap.add_argument("--sw-steps", type=int, default=10, help="passes over the Smith-Waterman batch (0 = skip that leg)")
     ap.add_argument("--smem-steps", type=int, default=10, help="passes over the SMEM read batch (0 = skip that leg)")
@@ -541,8 +594,17 @@ def main():
     import acc_genomics_amd as A
     from acc_genomics_amd import dist as D, synth
     mode = A.ACCG_PHMM_FAST if args.mode == "fast" else A.ACCG_PHMM_STRICT
+    # north_star's collective is the RCCL reduce: with more than one rank the run FAILS (non-zero status, a message naming RCCL)
+    # unless every rank's communicator is RCCL.  The ranks find out together, before any GPU is touched, whether all of them can
+    # load librccl (nobody is left waiting in ncclCommInitRank); --allow-comm-fallback is for rehearsals.
+    pre = None
+    if world > 1 and os.environ.get("ACCG_COMM_BACKEND", "rccl") == "rccl":
+        pre = D.rccl_preflight(rank, world)
+        if not pre[0] and not args.allow_comm_fallback:
+            sys.exit("bench.py: rank %d: RCCL is required for --gpus %d and cannot be loaded on every rank (%s); "
+                     "no line is printed (--allow-comm-fallback reduces the counters through files instead)" % (rank, world, pre[1]))
     ctx = A.Context(dev)
-    comm = D.open_comm(ctx, rank, world, allow_fallback=True)
+    comm = D.open_comm(ctx, rank, world, allow_fallback=args.allow_comm_fallback, preflight=pre)
     with_cpu = not args.no_cpu_baseline
 
     reads, haps = make_c1(rank)
@@ -558,14 +620,18 @@ def main():
     t1 = time.perf_counter()
     comm.barrier()
     elapsed = t1 - t0
+    # The dominant kernel timed INSIDE the step, at once behind the timed region so that both are taken in the same clock state:
+    # as many whole passes again (plain stream launches of the same kernels), each with HIP events around its fp32 sweep launch on
+    # the stream it is launched on (accg_phmm_batch_time_in_step); then the shader clock the card holds under load.
+    k_ms, step_ev_ms = batch.time_in_step(mode, iters=min(max(args.steps, 5), 1000))
+    clock_ghz = ctx.clock_ghz()
     raw, _, cnt = batch.results(want_log10=False)
-    # dominant kernel: the fp32 sweep alone, HIP events on the launch stream (accg_phmm_batch_time2), taken right behind the
-    # timed region (the later legs leave the card in a different power state: the same kernel then measures ~10 % slower)
-    k_ms = batch.time(mode, warmup=3, iters=50, fp32_pass_only=True)
 
-    # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks, wall time max over ranks (RCCL)
-    total_cells, total_pairs, _, total_resc, wall = comm.allreduce(batch.cells * args.steps, batch.pairs * args.steps,
-                                                                   int(k_ms * 1e6), int(cnt.rescued), elapsed)
+    # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks -- all four as totals over the timed steps -- and the
+    # wall time max over ranks (RCCL)
+    total_cells, total_pairs, total_kns, total_resc, wall = comm.allreduce(batch.cells * args.steps, batch.pairs * args.steps,
+                                                                           int(k_ms * 1e6) * args.steps, int(cnt.rescued) * args.steps, elapsed)
+    _, rccl_ranks, _, _, _ = comm.allreduce(0, 1 if comm.uses_rccl else 0, 0, 0, 0.0)
 
     def leg_reduce(units, seconds):
         u, _, _, _, t = comm.allreduce(units, 0, 0, 0, seconds)
@@ -606,22 +672,33 @@ def main():
                                             "right banded extension, 1/-4/-1, gaps 6+1, w 100"}}
             bwasw.update(bw_extras)
 
+    e2e = bench_e2e(ctx, reads, haps, args.e2e_regions, mode) if (rank == 0 and args.e2e_regions >= 0) else None
+
     line = None
     if rank == 0:
         algo = batch.algorithmic_bytes
         achieved = algo / (k_ms * 1e-3) / 1e9
-        # VALU view: report the algorithmic 12 flop/cell figure of SURVEY.md 8d against the fp32 vector peak as the binding roof
         flops = 12.0 * batch.cells / (k_ms * 1e-3)
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": PHMM_KERNEL_NAME, "kernel_ms": k_ms,
-                "algorithmic_bytes_per_launch": algo,
-                "valu": {"achieved_tflops": flops / 1e12, "peak_tflops": 157.3, "frac": flops / 157.3e12,
-                         "note": "12 algorithmic flop/cell (baseline_impl.cpp:84-86); the recurrence is VALU-issue bound, not HBM bound"}}
         tj = traffic().get("phmm_c1", {})            # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
-        roof["traffic"] = tj.get("hbm_bytes_per_launch")
-        roof["pmc"] = tj.get("counters")             # rocprofv3 --pmc passes of the same workload (LDS bank conflicts among them)
-        if tj.get("valu_insts_per_launch"):
-            roof["valu"]["issue"] = valu_issue(tj["valu_insts_per_launch"], k_ms, ubench_ns=1.32, waves_per_simd=2)
+        insts = tj.get("valu_insts_per_launch")
+        issue = valu_issue(insts, k_ms, ubench_ns=1.32, waves_per_simd=2) if insts else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": tj.get("hbm_bytes_per_launch"), "kernel": PHMM_KERNEL_NAME, "kernel_ms": k_ms,
+                "kernel_ms_how": "mean over %d whole passes run right behind the timed region, HIP events around the fp32 sweep launch "
+                                 "inside each pass (accg_phmm_batch_time_in_step); those passes took %.4f ms each" % (min(max(args.steps, 5), 1000), step_ev_ms),
+                "algorithmic_bytes_per_launch": algo,
+                # the roofs that bind (the kernel is fp32-VALU-issue bound, 6.6e-4 B/cell keeps HBM idle)
+                "binding": "fp32 VALU issue",
+                "valu_frac": flops / 157.3e12,
+                "issue_frac": issue["frac"] if issue else None,
+                "clock_ghz_held": clock_ghz,
+                "issue_frac_at_clock_held": (issue["ideal_ms"] * (CLOCK_HZ / 1e9) / clock_ghz / k_ms) if issue and clock_ghz > 0 else None,
+                "pmc_source": pmc_source(),
+                "valu": {"achieved_tflops": flops / 1e12, "peak_tflops": 157.3, "frac": flops / 157.3e12, "issue": issue,
+                         "note": "valu_frac = 12 algorithmic flop/cell (baseline_impl.cpp:84-86) x cells / kernel_ms / 157.3 TF; issue_frac = "
+                                 "SQ_INSTS_VALU per launch / 1024 SIMDs x 2 cycles / 2.4 GHz / kernel_ms (instruction count from pmc_source, "
+                                 "kernel_ms from this run); ..._at_clock_held prices the same cycles at the clock measured in this run"},
+                "pmc": tj.get("counters")}           # rocprofv3 --pmc passes of the same workload (LDS bank conflicts among them)
         cpu = cpu_baseline_phmm(reads, haps) if with_cpu else None
         check = None
         if with_cpu:                                 # the measured batch against the oracle on a sample (checker only, untimed)
@@ -638,7 +715,7 @@ def main():
             check = {"pairs_checked": len(idxs), "max_rel_err_log10": worst, "tolerance": 1e-5, "within_tolerance": bool(worst < 1e-5)}
         line = {
             "metric": "pairhmm_forward_gcups_fp32", "value": total_cells / wall / 1e9, "unit": "GCUPS",
-            "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "n_gpus": comm.world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: PairHMM 2048 reads (101 bp) x 32 haplotypes (300 bp) = 65536 pairs per GPU, "
                                    "fp32 sweep + fp64 rescue pass, mode=%s" % args.mode,
@@ -646,7 +723,9 @@ def main():
                        "collective": "rccl" if comm.uses_rccl else ("none (one rank)" if comm.world == 1 else
                                       comm.backend + (" (RCCL failed: %s)" % comm.fallback_reason if getattr(comm, "fallback_reason", None) else ""))},
             "roofline": roof, "cpu_baseline": cpu, "oracle_check": check,
-            "counters": {"cells": total_cells, "pairs": total_pairs, "rescued": total_resc},
+            "counters": {"cells": total_cells, "pairs": total_pairs, "kernel_ns": total_kns, "rescued": total_resc,
+                         "unit": "totals over the %d timed steps and all ranks" % args.steps},
+            "e2e": e2e,
             "c3": c3, "sw": sw, "smem": smem, "bwasw": bwasw,
         }
     batch.close()

@@ -91,6 +91,12 @@ int accg_phmm_batch_run_f64(accg_phmm_batch* b);
 int accg_phmm_batch_results_f64(accg_phmm_batch* b, double* out_raw64);
 /* fp32 pass only / whole run timing with hipEvents on the launch stream; what: 0 = fp32 + rescue, 1 = fp32 pass only */
 int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int warmup, int iters, float* ms_per_run);
+/* `iters` whole passes back to back with HIP events around each pass's fp32 sweep launches, on the stream they are launched on:
+ * kernel_ms = mean of the dominant kernel measured INSIDE the step, step_ms = mean whole pass (same run, same clock state) */
+int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float* kernel_ms, float* step_ms);
+/* the shader clock the device holds under load right now, in GHz: a ~0.3 ms full-chip fp32 kernel whose first wavefront reads the
+ * shader-clock counter and the constant-rate wall clock at both ends */
+int accg_ctx_clock_ghz(accg_ctx* ctx, float* ghz);
 uint64_t accg_phmm_batch_jobs(const accg_phmm_batch* b);
 /* Context<float>/<double> tables as uploaded (ph2pr[128], matchToMatchProb[8256], INITIAL_CONSTANT, its log10) */
 void accg_phmm_tables_f32(float* ph2pr, float* m2m, float* init, float* log10_init);
@@ -219,6 +225,9 @@ int accg_bwasw_records(accg_ctx* ctx, const int32_t* input, int64_t size, const 
 #define ACCG_COMM_ID_BYTES 128
 typedef struct accg_comm accg_comm;
 void accg_counters_pack(const accg_counters* c, uint64_t out[4]);
+/* ACCG_OK when librccl can be loaded (ACCG_RCCL_LIB names it, else the system's librccl.so), ACCG_ERR_NO_RCCL otherwise; needs no
+ * device.  Every rank calls it and the ranks compare notes BEFORE any of them enters accg_comm_init, which is collective. */
+int accg_comm_available(void);
 int accg_comm_unique_id(void* id_bytes);                       /* ncclGetUniqueId */
 int accg_comm_init(accg_ctx* ctx, int rank, int world, const void* id_bytes, accg_comm** out);   /* id may be NULL for world == 1 */
 int accg_comm_rank(const accg_comm* c);

@@ -35,6 +35,10 @@ float  orc_phmm_forward_f32_fma(int rslen, int haplen, const char* rs, const cha
 float  orc_phmm_forward_f32_fma6(int rslen, int haplen, const char* rs, const char* q, const char* qi,
                                  const char* qd, const char* qc, const char* hap);
 int    orc_phmm_x6_eligible(int rslen, const char* qi, const char* qc);
+/* five-operation form (reads that pass orc_phmm_x5_eligible); see phmm_oracle.c */
+float  orc_phmm_forward_f32_fma5(int rslen, int haplen, const char* rs, const char* q, const char* qi,
+                                 const char* qd, const char* qc, const char* hap);
+int    orc_phmm_x5_eligible(int rslen, const char* qi, const char* qd, const char* qc);
 
 /* Post-process of FalconPairHMM::computePairhmmAVX (FalconPairHMM.cpp:83-90):
  * raw < 1e-28f -> log10(fp64 forward) - log10(2^1020), else (double)(log10f(raw) - log10f(2^120)). */

@@ -240,6 +240,72 @@ float orc_phmm_forward_f32_fma6(int rslen, int haplen, const char* rs, const cha
   return res;
 }
 
+/* The five-operation form of the GPU fast mode: on top of Xs = X / pMX[r], Y is kept divided by the row's pMY and the diagonal
+ * term divided by the consumer row's pMM, which moves into that row's emission values:
+ *   Ys[r][c] = fma(Ys[r][c-1], pYY[r], M[r][c-1])                                 (Ys[0][c] = INIT/H: row 0 is scaled by 1)
+ *   T[r][c]  = fma(Ys[r][c], b[r], fma(Xs[r][c], a[r], M[r][c]))                 a[r] = (pMX[r] * pGM[r+1]) / pMM[r+1],
+ *                                                                                 b[r] = (sY[r]  * pGM[r+1]) / pMM[r+1], sY[0] = 1, sY[r] = pMY[r]
+ *   M[r][c]  = (dist(r,c) * pMM[r]) * T[r-1][c-1]
+ *   Xs and the result as in orc_phmm_forward_f32_fma6.
+ * Restates baseline_impl.cpp:84-86 / avx-pairhmm-template.h:183-198 with 5 instead of 12 operations per cell.  The kernel only takes
+ * this form for reads that pass orc_phmm_x5_eligible: the x6 bound, every pMM >= 1/16 (a, b and T stay within a factor 16 of the
+ * unscaled values) and every pYY <= 31/32 (Ys <= 32 max M).  Not a reference function: the GPU's arithmetic model. */
+int orc_phmm_x5_eligible(int rslen, const char* qi, const char* qd, const char* qc) {
+  ensure();
+  if (!orc_phmm_x6_eligible(rslen, qi, qc)) return 0;
+  for (int r = 0; r < rslen; r++) {
+    if (!(g_m2m_f[tri(qi[r] & 127, qd[r] & 127)] >= 0.0625f)) return 0;
+    if (!(g_ph_f[qc[r] & 127] <= 0.96875f)) return 0;
+  }
+  return 1;
+}
+float orc_phmm_forward_f32_fma5(int rslen, int haplen, const char* rs, const char* q, const char* qi,
+                                const char* qd, const char* qc, const char* hap) {
+  ensure();
+  FTZ_BEGIN;
+  int R = rslen, H = haplen;
+  /* T of the row above (previous column order), Xs of the row above, this row's M / Xs / T */
+  float* buf = (float*)malloc(sizeof(float) * 6 * (size_t)(H + 1));
+  float *Mp = buf, *Xp = Mp + H + 1, *Tp = Xp + H + 1, *Mc = Tp + H + 1, *Xc = Mc + H + 1, *Tc = Xc + H + 1;
+  /* row 0: M = X = 0, Ys = INIT/H, T[0][c] = fma(Ys, b[0], fma(0, a[0], 0)) with b[0] = (1 * pGM[1]) / pMM[1] */
+  {
+    float g1 = 1.0f - g_ph_f[qc[0] & 127], m1 = g_m2m_f[tri(qi[0] & 127, qd[0] & 127)];
+    float b0 = (1.0f * g1) / m1, y0 = g_init_f / (float)H;
+    for (int c = 0; c <= H; c++) { Mp[c] = 0.f; Xp[c] = 0.f; Tp[c] = fmaf(y0, b0, fmaf(0.f, 0.f, 0.f)); }
+  }
+  float pMXprev = 0.f;
+  for (int r = 1; r <= R; r++) {
+    int qi_ = qi[r - 1] & 127, qd_ = qd[r - 1] & 127, qc_ = qc[r - 1] & 127, qq_ = q[r - 1] & 127;
+    float pMM = g_m2m_f[tri(qi_, qd_)], pMX = g_ph_f[qi_], pYY = g_ph_f[qc_], pMY = g_ph_f[qd_];
+    float gnext = 0.f, mnext = 0.f;
+    if (r < R) { gnext = 1.0f - g_ph_f[qc[r] & 127]; mnext = g_m2m_f[tri(qi[r] & 127, qd[r] & 127)]; }
+    float a = r < R ? (pMX * gnext) / mnext : 0.f, b = r < R ? (pMY * gnext) / mnext : 0.f;
+    float cXc = (pYY * pMXprev) / pMX;               /* chain coefficient of Xs; 0 for the first row (pXX == pYY) */
+    float dmis = (g_ph_f[qq_] / 3.0f) * pMM, dmat = (1.0f - g_ph_f[qq_]) * pMM;
+    char rb = rs[r - 1];
+    Mc[0] = 0.f; Xc[0] = 0.f;
+    float ys = 0.f;                                  /* Ys[r][0] = 0 */
+    Tc[0] = 0.f;                                     /* never used: column 0 of the row below is the border */
+    for (int c = 1; c <= H; c++) {
+      char hb = hap[c - 1];
+      float dist = (rb == hb || rb == 'N' || hb == 'N') ? dmat : dmis;
+      Mc[c] = dist * Tp[c - 1];
+      Xc[c] = fmaf(Xp[c], cXc, Mp[c]);
+      ys = fmaf(ys, pYY, Mc[c - 1]);                 /* Ys[r][c] from Ys[r][c-1] and M[r][c-1] */
+      Tc[c] = fmaf(ys, b, fmaf(Xc[c], a, Mc[c]));
+    }
+    /* T[r][0] as the kernel computes it at a bubble: M = Xs = Ys = 0 -> 0; Tp[c-1] with c = 1 reads it */
+    float* t;
+    t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Tp; Tp = Tc; Tc = t;
+    pMXprev = pMX;
+  }
+  float res = 0.f;
+  for (int c = 1; c <= H; c++) res += fmaf(Xp[c], pMXprev, Mp[c]);
+  free(buf);
+  FTZ_END;
+  return res;
+}
+
 double orc_phmm_finish(float raw, int rslen, int haplen, const char* rs, const char* q, const char* qi,
                        const char* qd, const char* qc, const char* hap, int* rescued) {
   ensure();

@@ -34,7 +34,8 @@ def main():
         batch.close()
         comm.close()
     np.savez(out, raw=raw, l10=l10, shard=np.array([a, b]), rescued=int(cnt.rescued),
-             tot=np.array([tot["cells"], tot["pairs"], tot["rescued"]], np.int64), wall=tot["wall_s"],
+             tot=np.array([tot["cells"], tot["pairs"], tot["rescued"]], np.int64), wall=tot["wall_s"], kernel_ns=int(tot["kernel_ns"]),
+             per_rank_kernel_ns=np.array([r["kernel_ns"] for r in per_rank], np.int64),
              per_rank_cells=np.array([r["cells"] for r in per_rank], np.int64), per_rank_regions=np.array([r["regions"] for r in per_rank], np.int64))
 
 

@@ -44,6 +44,9 @@ def oracle():
         L.orc_phmm_forward_f32_fma6.restype = C.c_float
         L.orc_phmm_forward_f32_fma6.argtypes = pair
         L.orc_phmm_x6_eligible.argtypes = [C.c_int, C.c_char_p, C.c_char_p]
+        L.orc_phmm_forward_f32_fma5.restype = C.c_float
+        L.orc_phmm_forward_f32_fma5.argtypes = pair
+        L.orc_phmm_x5_eligible.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.orc_phmm_finish.restype = C.c_double
         L.orc_phmm_finish.argtypes = [C.c_float] + pair + [i32p]
         L.orc_phmm_region.restype = C.c_int

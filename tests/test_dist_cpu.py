@@ -124,3 +124,41 @@ def test_bench_gpus_flag_starts_ranks_and_reports_their_failure():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "rank" in r.stderr and "no gfx950 HIP device" in r.stderr
+
+
+def test_bench_multi_rank_requires_rccl():
+    """north_star's collective is the RCCL reduce: `--gpus 2` with a librccl that cannot be loaded must fail on every rank with a
+    message naming RCCL -- before any GPU is touched, so this runs anywhere -- and print no line."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACCG_RCCL_LIB="/nonexistent/librccl.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "RCCL is required" in r.stderr and "librccl not available" in r.stderr
+
+
+def _status_worker(rank, world, base, q):
+    q.put((rank, D.exchange_status(base, "pre", rank, world, rank != 1, "" if rank != 1 else "no librccl here", timeout=30)))
+
+
+def test_comm_decision_is_collective(tmp_path):
+    """One rank that cannot use RCCL is seen by EVERY rank (exchange_status), so all of them take the same branch."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    base = str(tmp_path / "id")
+    ps = [ctx.Process(target=_status_worker, args=(r, 3, base, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+    assert all(st == [(True, ""), (False, "no librccl here"), (True, "")] for _, st in res)
+
+
+def test_rendezvous_name_carries_a_per_run_nonce(monkeypatch):
+    monkeypatch.delenv("ACCG_COMM_FILE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    name = D.comm_file_default()
+    assert name.startswith("/tmp/accg_comm_29999_%d_" % os.getppid()) and name.split("_")[-1] not in ("", "0")

@@ -41,7 +41,8 @@ def test_two_ranks_one_gpu_equal_unsharded(tmp_path):
     assert got_raw.tobytes() == raw.tobytes()                      # bit for bit: sharding changes nothing in any pair
     assert got_l10.tobytes() == l10.tobytes()
     for q in z:                                                     # both ranks hold the same reduced counters
-        assert list(q["tot"]) == [cells * 2, pairs * 2, int(cnt.rescued)]      # 2 timed steps
+        assert list(q["tot"]) == [cells * 2, pairs * 2, int(cnt.rescued) * 2]      # totals over the 2 timed steps, every field
+        assert int(q["kernel_ns"]) == 2 * int(q["per_rank_kernel_ns"].sum()) > 0   # ... kernel time included: mean pass x steps
         assert list(q["per_rank_regions"]) == [b_ - a_ for a_, b_ in shards]
         assert int(q["per_rank_cells"].sum()) == cells
     assert sum(int(q["rescued"]) for q in z) == int(cnt.rescued) and int(cnt.rescued) > 0

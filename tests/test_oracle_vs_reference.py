@@ -82,7 +82,10 @@ def test_fma_model_within_budget():
             for h in haps:
                 a = orc.pair_args(r, h)
                 g = float(R.ref_phmm_avxs(*a))
-                for f in (float(O.orc_phmm_forward_f32_fma(*a)), float(O.orc_phmm_forward_f32_fma6(*a))):   # both fast forms
+                fs = [float(O.orc_phmm_forward_f32_fma(*a)), float(O.orc_phmm_forward_f32_fma6(*a))]          # every fast form
+                if O.orc_phmm_x5_eligible(len(r["b"]), r["i"], r["d"], r["c"]):
+                    fs.append(float(O.orc_phmm_forward_f32_fma5(*a)))
+                for f in fs:
                     if g > 1e-28:
                         worst = max(worst, abs(f - g) / g)
     assert worst < 1e-5, worst

@@ -63,50 +63,67 @@ def test_golden_fast_within_tolerance(ctx, path):
     assert not ok.any() or (np.abs(raw[ok] - g["raw_avx"][ok]) / g["raw_avx"][ok]).max() < REL_TOL
 
 
-def _model(O, r, h, x6):
+def _read_form(O, r):
+    """The cheapest form of the fast sweep a read passes the range tests of (phmm_host.cpp: phmm_read_form)."""
+    n = len(r["b"])
+    if O.orc_phmm_x5_eligible(n, r["i"], r["d"], r["c"]):
+        return 5
+    return 6 if O.orc_phmm_x6_eligible(n, r["i"], r["c"]) else 7
+
+
+def _model(O, r, h, form):
     a = orc.pair_args(r, h)
     if len(r["b"]) <= 15:                       # reads of at most 15 bases take the reference's operation order in fast mode too
         return O.orc_phmm_forward_f32(*a, 0)
-    return O.orc_phmm_forward_f32_fma6(*a) if x6 else O.orc_phmm_forward_f32_fma(*a)
+    return {5: O.orc_phmm_forward_f32_fma5, 6: O.orc_phmm_forward_f32_fma6, 7: O.orc_phmm_forward_f32_fma}[form](*a)
 
 
 def test_fast_matches_its_arithmetic_model(ctx, monkeypatch):
-    """The fast mode is bit-exact with the oracle's restatement of its own arithmetic -- the six-operation form for reads
-    that pass the range test (all of them here: smooth insertion qualities), the seven-operation form when that is switched off:
-    any difference is a kernel bug, not rounding."""
+    """The fast mode is bit-exact with the oracle's restatement of its own arithmetic -- the five-operation form for reads that pass
+    its range tests (all of them here: smooth qualities), the six- and seven-operation forms when the cheaper ones are switched
+    off: any difference is a kernel bug, not rounding."""
     O = orc.oracle()
     rng = synth.rng_for(300)
     reads, haps = synth.make_region(rng, 9, 5, (20, 120), (30, 200), n_frac=0.02, unrelated_frac=0.2)
-    assert all(O.orc_phmm_x6_eligible(len(r["b"]), r["i"], r["c"]) for r in reads)
-    for x6 in (True, False):
-        monkeypatch.setenv("ACCG_PHMM_X6", "1" if x6 else "0")
+    assert all(_read_form(O, r) == 5 for r in reads)
+    for form in (5, 6, 7):
+        monkeypatch.setenv("ACCG_PHMM_FORM", str(form))
         raw, _, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 45, A.ACCG_PHMM_FAST, want_log10=False)
         k = 0
         for r in reads:
             for h in haps:
-                assert np.float32(_model(O, r, h, x6)).tobytes() == raw[k].tobytes(), (x6, k)
+                assert np.float32(_model(O, r, h, form)).tobytes() == raw[k].tobytes(), (form, k)
                 k += 1
 
 
 def test_fast_mixed_eligibility(ctx):
     """Reads whose insertion qualities jump (1 -> 60 from one base to the next) fail the range test of the six-operation form
-    and run in the seven-operation one; a region mixes both kinds, every K class of 8- and 16-lane groups, and each read must
-    come out bit-equal to the model of the form it is eligible for."""
+    and run in the seven-operation one; reads with a gap-continuation quality of 0 somewhere (pYY = 1) or with a deletion
+    quality of 0 (pMM < 1/16) fail the five-operation form's and run in the six-operation one; a region mixes all
+    three kinds, every K class of 8- and 16-lane groups, and each read must come out bit-equal to the model of its form."""
     O = orc.oracle()
     rng = synth.rng_for(302)
-    reads, haps = synth.make_region(rng, 40, 3, (16, 200), (40, 260), unrelated_frac=0.1)
+    reads, haps = synth.make_region(rng, 60, 3, (16, 200), (40, 260), unrelated_frac=0.1)
     for j, r in enumerate(reads):
-        if j % 3 == 0:
+        if j % 4 == 0:
             qi = np.frombuffer(r["i"], np.uint8).copy()
             qi[::2] = 1; qi[1::2] = 60
             r["i"] = qi.tobytes()
-    elig = [bool(O.orc_phmm_x6_eligible(len(r["b"]), r["i"], r["c"])) for r in reads]
-    assert any(elig) and not all(elig)
-    raw, l10, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 120, A.ACCG_PHMM_FAST)
+        elif j % 4 == 1:
+            qc = np.frombuffer(r["c"], np.uint8).copy()
+            qc[len(qc) // 2] = 0
+            r["c"] = qc.tobytes()
+        elif j % 4 == 2 and j % 8 == 2:
+            qd = np.frombuffer(r["d"], np.uint8).copy()
+            qd[3] = 0
+            r["d"] = qd.tobytes()
+    forms = [_read_form(O, r) for r in reads]
+    assert set(forms) == {5, 6, 7}
+    raw, l10, _ = ctx.phmm_region(synth.serialize_reads(reads), synth.serialize_haps(haps), 180, A.ACCG_PHMM_FAST)
     k = 0
-    for r, e in zip(reads, elig):
+    for r, f in zip(reads, forms):
         for h in haps:
-            assert np.float32(_model(O, r, h, e)).tobytes() == raw[k].tobytes(), (k, e)
+            assert np.float32(_model(O, r, h, f)).tobytes() == raw[k].tobytes(), (k, f)
             k += 1
     _, want, _ = _oracle_region(reads, haps)
     assert (np.abs(l10 - want) / np.abs(want)).max() < REL_TOL

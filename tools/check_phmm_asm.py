@@ -104,7 +104,8 @@ def main():
             continue
         ins = [l.split("//")[0].strip() for l in body if l and not l.startswith(";")]
         seen += 1
-        m = re.search(r"phmm_kernelI([fd])Li(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])", name)
+        # phmm_kernel<T, K, LPP, STRICT, RESCUE, XF (0 / 6 / 5: operations per cell of the fast sweep), STRIPED>
+        m = re.search(r"phmm_kernelI([fd])Li(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])", name)
         asm_col = bool(m) and m.group(4) == "0" and m.group(7) == "0" and (m.group(1) == "f" or int(m.group(2)) <= 10)
         hand += asm_col
         if not asm_col:       # compiler-managed waits: its own s_waitcnt insertion follows the control flow, which this linear replay does not
