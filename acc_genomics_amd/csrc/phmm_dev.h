@@ -31,11 +31,21 @@ constexpr int phmm_slab_bytes(int K, int elem_bytes, bool compact) {
 constexpr int PHMM_ASM_MAX_K_F64 = 10;
 constexpr bool phmm_is_compact(int elem_bytes, bool strict, int K = 1) { return !strict && (elem_bytes == 4 || K <= PHMM_ASM_MAX_K_F64); }
 // striped (reads longer than 64 x 16 - 1 bases): two carry arrays of one value per stream position behind the stream
+// ... per wavefront: everything but the dist table ([y0][hcol][bpos][stream], and the carry arrays of a striped read)
+// (+ 64 bytes at its end: {output row, read index} of the wavefront's up to eight reads, which only the off-the-hot-path code of the
+// sweep needs -- held there they take no registers in the sweep)
+constexpr size_t PHMM_STASH_BYTES = 64;
+constexpr size_t phmm_wave_area_bytes(int elem_bytes, int stream_cap, int haps_cap, int lpp = 16, bool striped = false) {
+  return phmm_align16((size_t)(haps_cap + 1) * elem_bytes) + phmm_align16((size_t)(2 * haps_cap + 3) * 4) +
+         phmm_align16((size_t)2 * lpp + stream_cap + 24) + (striped ? phmm_align16((size_t)2 * elem_bytes * (stream_cap + 2 * lpp + 24)) : 0) +
+         PHMM_STASH_BYTES;
+}
+// wg = wavefronts per workgroup: 1, or 2 that hold the SAME reads against different runs of haplotypes and share one dist table
+// (the table depends on the reads only): [dist table][wave 0's area][wave 1's area]
 constexpr size_t phmm_lds_bytes(int K, int elem_bytes, int nchar, int stream_cap, int haps_cap, int lpp = 16, bool compact = false,
-                                bool striped = false) {
-  return (size_t)nchar * phmm_slab_bytes(K, elem_bytes, compact && !striped) + phmm_align16((size_t)(haps_cap + 1) * elem_bytes) +
-         phmm_align16((size_t)(2 * haps_cap + 3) * 4) + phmm_align16((size_t)2 * lpp + stream_cap + 24) +
-         (striped ? (size_t)2 * elem_bytes * (stream_cap + 2 * lpp + 24) : 0);
+                                bool striped = false, int wg = 1) {
+  return (size_t)nchar * phmm_slab_bytes(K, elem_bytes, compact && !striped) +
+         (size_t)wg * phmm_wave_area_bytes(elem_bytes, stream_cap, haps_cap, lpp, striped);
 }
 constexpr uint32_t PHMM_NO_READ = 0xFFFFFFFFu;
 
@@ -135,7 +145,10 @@ void phmm_pick(uint32_t read_len, int* lpp, int* K, int max_k8 = 0);        // r
 inline bool phmm_striped(uint32_t read_len) { return read_len + 1 > 1024; }
 // form (fast mode only): 7, 6 or 5 operations per cell; a wavefront runs the six- / five-operation form only if all of its reads pass
 // the form's range test (phmm_host.cpp: phmm_read_form)
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, int form, bool striped, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);
+// wg = 2 (fast mode, not striped): consecutive pairs of work items hold the same reads and run as one workgroup of two wavefronts
+// sharing the dist table in LDS (n_work even; a pair's second item may be empty, n_haps = 0)
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, int form, bool striped, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s,
+                           int wg = 1);
 // The six-operation form keeps X divided by the row's pMX: Xs[r] = M[r-1] + c[r] Xs[r-1], c[r] = pXX[r] pMX[r-1] / pMX[r].
 // Xs is bounded by max(M) * F, F[r] = 1 + c[r] F[r-1]; M never exceeds INIT / H <= 2^120, so F <= 32 leaves a factor of 8 to
 // FLT_MAX.  Reads whose insertion qualities jump by more than ~7 dB from one base to the next push F up and stay in the

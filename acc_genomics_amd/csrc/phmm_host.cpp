@@ -212,7 +212,9 @@ extern "C" void accg_phmm_tables_f64(double* ph128, double* m2m8256, double* ini
 namespace {
 
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
-struct KLaunch { int K, lpp, form; bool striped; uint32_t work0, n_work; int stream_cap, haps_cap; };   // form: 7, 6 or 5 operations per cell
+// form: 7, 6 or 5 operations per cell; wg = 2: the work items come in pairs (same reads, two runs of haplotypes; the second may be
+// empty) that the fast kernel runs as one workgroup of two wavefronts sharing the dist table
+struct KLaunch { int K, lpp, form; bool striped; int wg; uint32_t work0, n_work; int stream_cap, haps_cap; };
 
 thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
 struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
@@ -353,12 +355,18 @@ int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<Se
 // Resident wavefronts per CU for the fp32 kernel at K rows per lane: LDS (160 KiB, granted in 512-byte units) and VGPR (512
 // per SIMD lane, in units of 8) limits.  Registers as the build reports them (kernel-resource-usage): 9 K + 23 for the fast
 // kernel (column in assembly), 13 K + 23 for the strict one (compiler-scheduled).
-int waves_per_cu(int K, int nchar, int stream_cap, int haps_cap, int lpp, bool strict = false) {
-  const size_t lds = (phmm_lds_bytes(K, 4, nchar, stream_cap, haps_cap, lpp, !strict) + 511) / 512 * 512;
-  const int by_lds = (int)((160 * 1024) / lds);
-  const int vgpr = ((strict ? 13 : 9) * K + 23 + 7) / 8 * 8;
+// (form 5, the five-operation column: 8 K + 24; wg = wavefronts per workgroup sharing one dist table)
+int waves_per_cu(int K, int nchar, int stream_cap, int haps_cap, int lpp, bool strict = false, int form = 6, int wg = 1) {
+  const size_t lds = (phmm_lds_bytes(K, 4, nchar, stream_cap, haps_cap, lpp, !strict, false, wg) + 511) / 512 * 512;
+  const int by_lds = (int)((160 * 1024) / lds) * wg;
+  const int vgpr = ((strict ? 13 * K + 23 : form == 5 ? 8 * K + 24 : 9 * K + 23) + 7) / 8 * 8;
   const int by_vgpr = std::min(8, 512 / vgpr) * 4;
   return std::max(1, std::min(std::min(by_lds, by_vgpr), 32));
+}
+// Pairs pay where one wavefront per workgroup leaves a CU below sixteen wavefronts for want of LDS and two reach them
+bool pairs_pay(int K, int nchar, int stream_cap, int haps_cap, int lpp) {
+  static const bool off = [] { const char* e = getenv("ACCG_PHMM_WG"); return e && e[0] == '1'; }();     // A/B knob: 1 = never pair
+  return !off && waves_per_cu(K, nchar, stream_cap, haps_cap, lpp, false, 5, 1) < 16 && waves_per_cu(K, nchar, stream_cap, haps_cap, lpp, false, 5, 2) >= 16;
 }
 // The occupancy a launch is pinned to: 8, 16 or 32 wavefronts per CU, i.e. 2, 4 or 8 per SIMD on every SIMD (see partition()).
 int pinned_wpc(int natural) { return natural >= 32 ? 32 : natural >= 16 ? 16 : natural >= 8 ? 8 : natural; }
@@ -404,6 +412,7 @@ void partition(accg_phmm_batch& b) {
   b.sorted_reads.assign(b.rd.size(), 0);
   b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
   uint64_t kw[4][PHMM_MAX_K + 1] = {{0}};     // haplotype passes per (lanes per read: 8, 16, 32, 64; K)
+  uint64_t n_form5 = 0, n_other = 0;          // ... in the five-operation form (whose jobs may go in pairs) / in the others
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     const Region& r = b.regions[ri];
     if (r.n_reads == 0 || r.n_haps == 0) continue;
@@ -433,6 +442,7 @@ void partition(accg_phmm_batch& b) {
       i += take ? take : 1;                                    // (the first read always qualifies for its own group)
       groups[ri].push_back(Q);
       kw[Q.lpp == 8 ? 0 : Q.lpp == 16 ? 1 : Q.lpp == 32 ? 2 : 3][Q.K] += (uint64_t)r.n_haps;
+      (Q.form == 5 && !Q.striped ? n_form5 : n_other) += (uint64_t)r.n_haps;
     }
   }
   int K_dom = 1, lpp_dom = 16, n_classes = 0;
@@ -461,6 +471,7 @@ void partition(accg_phmm_batch& b) {
   const double prologue_steps = 30.0;   // table lookups + dist table + stream build, in units of one sweep step
   uint64_t best_budget = cand[0];
   double best_span = -1;
+  bool best_pairs = false;       // the schedule that won was simulated with the dominant class's jobs in pairs
   // Jobs take few distinct costs (chunk length x rows per lane), so the longest-first list schedule is simulated on
   // histograms: job costs in descending order, slot loads as load -> number of slots.  Assigning k equal jobs to the k
   // least-loaded slots of one bucket is what the sequential rule does one job at a time.
@@ -468,7 +479,14 @@ void partition(accg_phmm_batch& b) {
   std::map<double, uint64_t> loads;
   std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
   uint64_t seen_sig = 0;
-  for (uint64_t budget : cand) {
+  bool last_pairs_pay = false;
+  // The jobs of the dominant class go in pairs (one workgroup of two wavefronts sharing the dist table) when that buys occupancy;
+  // the schedule is then simulated on pairs and workgroup slots.  Whether it does depends on the stream length, i.e. on the budget:
+  // each candidate is simulated singly first and, if pairs would pay at its caps, again in pairs.
+  for (int pass = 0; pass < 2 * (int)cand.size(); pass++) {
+    const uint64_t budget = cand[pass / 2];
+    const bool sim_pairs = pass & 1;
+    if (sim_pairs && !(n_form5 >= n_other && last_pairs_pay)) continue;
     hist.clear();
     uint32_t cap = 0, hmax = 1;
     uint64_t n_jobs = 0, sig = 1469598103934665603ull;
@@ -480,15 +498,24 @@ void partition(accg_phmm_batch& b) {
       for (const auto& run : runs) hmax = std::max(hmax, run.second);
       sig = (sig ^ 0xFFFFFFFFull) * 1099511628211ull;
       int lastK = -1; uint64_t mult = 0;                       // groups are sorted by length: equal K come in runs
-      auto flush = [&]() { if (mult) for (uint32_t len : lens) hist[(len + 15 + prologue_steps) * (7.0 * lastK + 10.0)] += mult; };
+      // (pairs: a workgroup of two wavefronts lasts as long as the longer of its two runs)
+      auto flush = [&]() {
+        if (!mult) return;
+        for (size_t c = 0; c < lens.size(); c += sim_pairs ? 2 : 1) {
+          const uint32_t len = sim_pairs && c + 1 < lens.size() ? std::max(lens[c], lens[c + 1]) : lens[c];
+          hist[(len + 15 + prologue_steps) * (7.0 * lastK + 10.0)] += mult;
+        }
+      };
       for (const Group& Q : groups[ri]) {
         if (Q.K != lastK) { flush(); lastK = Q.K; mult = 0; }
         mult++;
       }
       flush();
-      n_jobs += (uint64_t)groups[ri].size() * lens.size();
+      n_jobs += (uint64_t)groups[ri].size() * (sim_pairs ? (lens.size() + 1) / 2 : lens.size());
     }
     if (n_jobs == 0) break;
+    sig = (sig ^ (sim_pairs ? 2u : 1u)) * 1099511628211ull;
+    if (!sim_pairs) last_pairs_pay = lpp_dom * K_dom > 16 && pairs_pay(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom);
     if (sig == seen_sig) continue;                             // same chunking as the previous candidate
     seen_sig = sig;
     // Resident wavefronts per CU: what registers and LDS allow, or fewer on purpose.  tools/ubench2.hip: the instruction mix of the
@@ -496,11 +523,12 @@ void partition(accg_phmm_batch& b) {
     // 5 ns for a wavefront that has its SIMD to itself -- a third wavefront per SIMD buys nothing, an odd one per CU unbalances the
     // SIMDs and a lone one at the tail is slow.  So the occupancy is one of 8, 16 or 32 per CU (the launches ask for as much LDS
     // as it takes to get exactly that), and a slot's speed is its SIMD's rate divided by the wavefronts sharing it.
-    const int wpc_max = waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom);
+    const bool dom5 = n_form5 >= n_other;
+    const int wpc_max = waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom, false, dom5 ? 5 : 6, sim_pairs ? 2 : 1);
     {
       const int wpc = force_wpc > 0 ? std::min(force_wpc, wpc_max) : force_wpc < 0 ? wpc_max : pinned_wpc(wpc_max);
       const int w = std::max(1, wpc / 4);
-      const int slots = n_cu * wpc;
+      const int slots = n_cu * wpc / (sim_pairs ? 2 : 1);
       loads.clear();
       loads[0.0] = (uint64_t)slots;
       for (const auto& hc : hist) {
@@ -514,7 +542,10 @@ void partition(accg_phmm_batch& b) {
           left -= k;
         }
       }
-      const double rate = w >= 8 ? 1.07 : w >= 4 ? 1.26 : w == 3 ? 1.34 : w == 2 ? 1.32 : 5.0;
+      // (five-operation column, three VOP3 in five: 1.46 measured at 2 wavefronts per SIMD, VOP3 1.6 / 1.37 / 1.2 / 1.03 and
+      // VOP2 1.3 / 1.32 / 1.14 / 1.0 ns at 2 / 3 / 4 / 8)
+      const double rate = dom5 ? (w >= 8 ? 1.02 : w >= 4 ? 1.17 : w == 3 ? 1.35 : w == 2 ? 1.46 : 5.0)
+                               : (w >= 8 ? 1.07 : w >= 4 ? 1.26 : w == 3 ? 1.34 : w == 2 ? 1.32 : 5.0);
       double span = loads.rbegin()->first * rate * w;
       // the hardware dispatcher is not an ideal list scheduler, and a slot that runs out of jobs early leaves its SIMD partner
       // alone at a quarter of the issue rate: a mild preference for several jobs per slot
@@ -525,18 +556,20 @@ void partition(accg_phmm_batch& b) {
       // long streams cost LDS (occupancy of the launches with few rows per lane) and lengthen the tail of every launch: measured
       // on the configs[3] mix +1 % at 2048 entries and +4.5 % at 4096 against 1300 (tools/sweep_c3.sh)
       if (cap > 1300) span *= 1.0 + 0.03 * ((double)cap - 1300.0) / 1024.0;
-      if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; }
+      if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; best_pairs = sim_pairs; }
     }
   }
 
-  struct Job { PhmmWork w; int K, lpp, form; bool striped; uint64_t cost; uint32_t stream_len; };
+  struct Job { PhmmWork w, w2; int K, lpp, form; bool striped; int wg; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
+  uint32_t cap_all = 0, hmax_all = 1;
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (groups[ri].empty()) continue;
     const Region& r = b.regions[ri];
     std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
     chunk_region(b, r, best_budget, runs, lens);
     std::vector<uint32_t> ids0;
+    for (size_t c = 0; c < runs.size(); c++) { cap_all = std::max(cap_all, (lens[c] + 63) / 64 * 64); hmax_all = std::max(hmax_all, runs[c].second); }
     b.regions_dev[ri] = {r.read0, r.n_reads, (uint32_t)b.chunks_dev.size(), (uint32_t)runs.size(), r.n_haps, 0};
     for (size_t c = 0; c < runs.size(); c++) {
       auto& run = runs[c];
@@ -555,28 +588,40 @@ void partition(accg_phmm_batch& b) {
       PhmmWork w;
       for (int g = 0; g < PHMM_GROUPS; g++) w.read[g] = Q.read[g];
       w.pad_[0] = w.pad_[1] = 0;
-      for (size_t c = 0; c < runs.size(); c++) {
+      // pairs of runs for one workgroup of two wavefronts (same reads, one dist table): five-operation form only, not the short
+      // reads that run in the reference's operation order, and only where it buys occupancy.  (cap_all / hmax_all: the LDS caps so far
+      // -- a launch's own caps are only known at the end; this one decision may come out differently for the first regions of a batch.)
+      const bool pair = best_pairs && Q.form == 5 && !Q.striped && Q.lpp * Q.K > 16 && pairs_pay(Q.K, nchar, (int)cap_all, (int)hmax_all, Q.lpp);
+      for (size_t c = 0; c < runs.size(); c += pair ? 2 : 1) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
+        PhmmWork w2 = w;
+        uint32_t len = lens[c];
+        if (pair) {
+          if (c + 1 < runs.size()) { w2.hap_off = ids0[c + 1]; w2.n_haps = runs[c + 1].second; len = std::max(len, lens[c + 1]); }
+          else { w2.hap_off = 0; w2.n_haps = 0; }
+        }
         const uint64_t stripes = Q.striped ? (b.rd[Q.read[0]].len + 1024) / 1024 : 1;
-        jobs.push_back({w, Q.K, Q.lpp, Q.form, Q.striped, stripes * (uint64_t)(lens[c] + 45) * (uint64_t)(8 * Q.K + 10), lens[c]});
+        jobs.push_back({w, w2, Q.K, Q.lpp, Q.form, Q.striped, pair ? 2 : 1, stripes * (uint64_t)(len + 45) * (uint64_t)(8 * Q.K + 10), len});
       }
     }
   }
   // one launch per K; inside a launch the longest jobs go first so the tail is short
   std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
-    return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.form != y.form ? x.form < y.form
+    return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.form != y.form ? x.form < y.form : x.wg != y.wg ? x.wg > y.wg
                                                                                                                                 : x.cost > y.cost;
   });
-  b.work.resize(jobs.size());
+  b.work.clear();
+  b.work.reserve(jobs.size() * 2);
   for (size_t i = 0; i < jobs.size(); i++) {
-    b.work[i] = jobs[i].w;
     if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().form != jobs[i].form ||
-        b.launches.back().striped != jobs[i].striped)
-      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].form, jobs[i].striped, (uint32_t)i, 0, 0, 0});
+        b.launches.back().striped != jobs[i].striped || b.launches.back().wg != jobs[i].wg)
+      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].form, jobs[i].striped, jobs[i].wg, (uint32_t)b.work.size(), 0, 0, 0});
     KLaunch& L = b.launches.back();
-    L.n_work++;
+    b.work.push_back(jobs[i].w);
+    if (jobs[i].wg == 2) b.work.push_back(jobs[i].w2);
+    L.n_work += (uint32_t)jobs[i].wg;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
-    L.haps_cap = std::max(L.haps_cap, (int)jobs[i].w.n_haps);
+    L.haps_cap = std::max(L.haps_cap, (int)std::max(jobs[i].w.n_haps, jobs[i].wg == 2 ? jobs[i].w2.n_haps : 0u));
   }
 }
 
@@ -610,17 +655,18 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : b->ctx->stream;
     const bool strict_l = mode == ACCG_PHMM_STRICT || l.lpp * l.K <= 16;
     // pinned occupancy: the launch asks for as much LDS as leaves exactly 8, 16 or 32 of its wavefronts on a CU
-    const int natural = waves_per_cu(l.K, a.nchar, l.stream_cap, l.haps_cap, l.lpp, strict_l);
+    const int wg = strict_l ? 1 : l.wg;         // a strict launch runs the items of a pair as two wavefronts of their own
+    const int natural = waves_per_cu(l.K, a.nchar, l.stream_cap, l.haps_cap, l.lpp, strict_l, l.form, wg);
     // (the compiled strict column is VOP3-heavy and does gain from a third wavefront per SIMD: any multiple of four for it)
     const int wpc = b->force_wpc > 0 ? std::min(b->force_wpc, natural) : b->force_wpc < 0 ? natural
                     : strict_l ? std::max(natural / 4 * 4, std::min(natural, 4)) : pinned_wpc(natural);
-    a.lds_min = (int)((160 * 1024 / std::max(wpc, 1)) / 512 * 512);
+    a.lds_min = (int)((160 * 1024 / std::max(wpc / wg, 1)) / 512 * 512);     // per workgroup
     // Reads of at most 15 bases take the reference's operation order in fast mode too: their log10 is close to 0, where the
     // reference's float `log10f(x) - log10f(2^120)` has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
     // cleared: with them contracted the worst case over 1 500 random regions stays at that granularity, 2.4e-6.
     if (l.striped) a.lds_min = 0;                   // one long read per wavefront and a large LDS block: nothing to pin
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, strict_l ? 7 : l.form, l.striped, a, l.work0, l.n_work, st));
+    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, strict_l ? 7 : l.form, l.striped, a, l.work0, l.n_work, st, wg));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   if (ev_end) ACCG_HIP(hipEventRecord(ev_end, b->ctx->stream));

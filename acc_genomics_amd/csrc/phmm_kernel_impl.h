@@ -595,32 +595,72 @@ template <int K> struct AsmCol<double, K> {
 // would cap the fp64 rescue kernel's LDS).
 #ifdef PHMM_TIMING
 static __device__ unsigned long long g_phmm_t[8];
+static __device__ unsigned long long g_phmm_w[4] = {~0ull, 0ull, ~0ull, 0ull};   // wall clock: first / last job start, first / last job end (last launch)
+// where the jobs of the last launch ran: wavefronts per (XCD, shader engine, CU, SIMD) and their durations
+static __device__ unsigned g_phmm_simd_n[32768];
+static __device__ unsigned long long g_phmm_simd_t[32768];
+static __global__ void phmm_timing_reset_wall() {
+  g_phmm_w[0] = g_phmm_w[2] = ~0ull; g_phmm_w[1] = g_phmm_w[3] = 0;
+  for (int i = 0; i < 32768; i++) { g_phmm_simd_n[i] = 0; g_phmm_simd_t[i] = 0; }
+}
 static __global__ void phmm_timing_print() {
   const double n = (double)g_phmm_t[0];
-  printf("phmm timing per job (s_memtime ticks): prologue %.0f = stream %.0f + row loads %.0f + dist table %.0f + rest %.0f; sweep %.0f\n", g_phmm_t[1] / n,
-         g_phmm_t[3] / n, g_phmm_t[4] / n, g_phmm_t[5] / n, g_phmm_t[6] / n, g_phmm_t[2] / n);
+  printf("phmm timing per job (s_memtime ticks): prologue %.0f = stream %.0f + row loads %.0f + dist table %.0f + rest %.0f; sweep %.0f; shader clock over the job %.3f GHz\n", g_phmm_t[1] / n,
+         g_phmm_t[3] / n, g_phmm_t[4] / n, g_phmm_t[5] / n, g_phmm_t[6] / n, g_phmm_t[2] / n, (double)(g_phmm_t[1] + g_phmm_t[2]) / (double)g_phmm_t[7] * 0.1);
+  printf("  last launch (wall clock, us): job starts spread over %.1f, first start to first end %.1f, to last end %.1f\n", (g_phmm_w[1] - g_phmm_w[0]) * 0.01,
+         (g_phmm_w[2] - g_phmm_w[0]) * 0.01, (g_phmm_w[3] - g_phmm_w[0]) * 0.01);
+  {
+    unsigned hist[12] = {0}; double tsum[12] = {0}; unsigned cu_hist[40] = {0};
+    for (int cu = 0; cu < 32768 / 4; cu++) {
+      unsigned tot = 0;
+      for (int sd = 0; sd < 4; sd++) {
+        const int i = (cu >> 8) * 1024 + ((cu & 255) << 2 | sd);       // key = xcc[14:12] : hw_id[15:6] : simd -- see the recording side
+        (void)i;
+      }
+      (void)tot;
+    }
+    for (int i = 0; i < 32768; i++) {
+      const unsigned n = g_phmm_simd_n[i];
+      if (n) { hist[n < 11 ? n : 11]++; tsum[n < 11 ? n : 11] += (double)g_phmm_simd_t[i] / n; }
+    }
+    for (int i = 0; i < 32768; i += 4) { const unsigned t = g_phmm_simd_n[i] + g_phmm_simd_n[i + 1] + g_phmm_simd_n[i + 2] + g_phmm_simd_n[i + 3]; if (t) cu_hist[t < 39 ? t : 39]++; }
+    printf("  SIMDs by wavefronts of the last launch they ran (count: mean job us):");
+    for (int n = 1; n < 12; n++) if (hist[n]) printf("  %d waves: %u SIMDs, %.1f us", n, hist[n], tsum[n] / hist[n] * 0.01);
+    printf("\n  CUs by wavefronts:");
+    for (int n = 1; n < 40; n++) if (cu_hist[n]) printf("  %d: %u", n, cu_hist[n]);
+    printf("\n");
+  }
   for (int i = 0; i < 8; i++) g_phmm_t[i] = 0;
+  g_phmm_w[0] = g_phmm_w[2] = ~0ull; g_phmm_w[1] = g_phmm_w[3] = 0;
 }
 #endif
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false>
+// W = wavefronts per workgroup: 1, or 2 whose jobs (work items 2 b and 2 b + 1 of the launch) list the SAME reads against different
+// runs of haplotypes.  The dist table depends on the reads only, so the two share one (each writes half of its slabs) and only the
+// stream and its bookkeeping are per wavefront: 13.3 + 2 x 1.4 KB for two wavefronts at K = 13 instead of 2 x 14.7 -- sixteen
+// wavefronts on a CU instead of ten, i.e. four per SIMD, where a VOP3 instruction issues in 1.2 ns instead of 1.6
+// (profiles/r02_ubench2.txt; the five-operation column is three VOP3 fmas in five).
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false, int W = 1>
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool X6 = XF == 6, X5 = XF == 5;     // six- / five-operation form of the fp32 fast sweep (0: seven operations)
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT, K) && !STRIPED;
   constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
+  static_assert(W == 1 || (!RESCUE && !STRIPED), "shared-table workgroups: the plain fp32 / fp64 passes only");
   unsigned char* tab = smem;
-  T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB);
+  const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB + (W > 1 ? wave * (int)phmm_wave_area_bytes((int)sizeof(T), a.stream_cap, a.haps_cap, LPP, STRIPED) : 0));
   uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
   uint32_t* bpos = hcol + a.haps_cap + 1;
   uint8_t* stream = reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4);
+  uint2* stash = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y0s) + phmm_wave_area_bytes((int)sizeof(T), a.stream_cap, a.haps_cap, LPP, STRIPED) - PHMM_STASH_BYTES);
   // striped reads (more rows than a wavefront holds): what the last lane hands "to the right", per stream position, for the next stripe
   T* carry_a = reinterpret_cast<T*>(stream + phmm_align16((size_t)2 * LPP + a.stream_cap + 24));
   T* carry_x = carry_a + (a.stream_cap + 2 * LPP + 24);
 
-  const int lane = threadIdx.x;
+  const int lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
 #ifdef PHMM_TIMING
-  const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime(), tw0 = wall_clock64();     // (wall clock: 100 MHz)
 #endif
   constexpr int NG = 64 / LPP;              // reads per wavefront
   const int g = lane / LPP, l = lane % LPP;
@@ -628,12 +668,14 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   const PhmmWork* wp = a.work + (work_base + job);
   const int n_list = __builtin_amdgcn_readfirstlane((int)wp->n_haps);
   const uint32_t hap_off = __builtin_amdgcn_readfirstlane(wp->hap_off);
+  if (W == 1 && n_list == 0) return false;     // the empty second item of an odd pair (phmm_host.cpp), met by a kernel that runs items singly
 
   const uint32_t ridx = wp->read[g < NG ? g : 0];
   const bool have = ridx != PHMM_NO_READ;
   SeqRef rr = {0u, 0u};
   uint32_t out_base = 0;
   if (have) { rr = a.rd[ridx]; out_base = a.rd_out[ridx]; }
+  if (g < NG && l == LPP - 1) stash[g] = make_uint2(out_base, ridx);      // for the off-the-hot-path code of the assembly sweep
 
   // ---- haplotype stream: [15 pad] bubble hap0 bubble hap1 ... bubble(terminal) [pad] ----------
   // an entry is the byte offset of its base's slab in the dist table; bubbles/padding use slab 0
@@ -760,6 +802,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #pragma unroll
     for (int c = 0; c < 5; c++) {
       if (c >= a.nchar) break;
+      if (W > 1 && (c % W) != wave) continue;       // the workgroup's wavefronts hold the same reads: each writes its share of the slabs
       V v;
 #pragma unroll
       for (int e = 0; e < VN; e++)   // rs == hap || rs == 'N' || hap == 'N'   (baseline_impl.cpp:80)
@@ -837,8 +880,13 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     }
   }
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's LDS writes (table, stream) before its own reads
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (W > 1) {
+    __syncthreads();                                        // the other wavefront's slabs of the table
+    if (n_list == 0) return false;                          // the empty second job of an odd pair: it has done its share of the table
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's LDS writes (table, stream) before its own reads
+    __builtin_amdgcn_wave_barrier();
+  }
 
   // ---- sweep ----------------------------------------------------------------------------------
   const uint8_t* hs = stream + LPP - 1 - l;           // hs[t] = this lane's column at step t (base index 0..4)
@@ -881,8 +929,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 #ifdef PHMM_TIMING
     const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
+    unsigned hs_cur = hs_a;            // LDS address of this lane's stream byte of step t: the ONE register the stream takes in the sweep
     while (t < t_stop) {
-      const unsigned hs_t = hs_a + (unsigned)t;
 #pragma unroll
       for (int u = 0; u < U; u++) {
         // the stream byte issued one step ago has landed: address of the next step's slab and its bubble flag, next byte on its way
@@ -891,7 +939,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         // (the wait also covers the first quad of dist values, the load right behind the byte: NLD - 1 younger ones may be in flight)
         asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_cmp_eq_u32 vcc, %3, %1\n\ts_or_b32 %0, vcc_lo, vcc_hi" : "=s"(any_next) : "v"(o1n), "n"(NLD - 1), "s"(nchar_s) : "vcc", "scc");
         asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr_next) : "v"(o1n), "s"(slab_s), "v"(tab_a));
-        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_t), "n"(u + 2));
+        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(o1n) : "v"(hs_cur), "n"(u + 2));
         const T contrib = AsmCol<T, K>::template column<LPP, XF>(s, dq, addr_next, tail_adj);
         const T acc_done = s.acc;            // the running sum up to the step before: what a bubble lane reports
         s.acc = s.acc + contrib;             // (added before the branch: a bubble lane overwrites the sum, there is no second value of contrib to merge)
@@ -901,17 +949,26 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
           // where they are dead, it reuses one as an address register while the load is still on its way (tools/check_phmm_asm.py).
           // (the step index and the lane's haplotype counter pass through the statement, so that nothing below -- all of it hangs on
           // one of the two -- is scheduled in front of the wait)
-          int tu = t + u;
-          asm volatile("; bubble step\n\ts_waitcnt lgkmcnt(0)" : "+s"(tu), "+v"(jl));
+          // (... and the lane's own stream byte of this step is fetched again by the same statement, from the sweep's own address
+          // register: read through the `hs` pointer it cost two more registers, live across the whole loop)
+          unsigned mine;
+          asm volatile("; bubble step\n\ts_waitcnt lgkmcnt(0)\n\tds_read_u8 %0, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(mine), "+v"(jl) : "v"(hs_cur), "n"(u));
           // Some lane (one per group) is on a bubble = column 0 of its next haplotype.  Everybody ran the ordinary column; that
           // lane now overwrites its state with the column-0 border (M = X = 0, Y = 0, clones of row 0: Y = INIT/H;
           // baseline_impl.cpp:60-70) under EXEC.  Which lane: the one whose own stream byte of this step is the marker (read again
           // here, off the hot path).
-          if (hs[tu] == (uint8_t)nchar_s) {
+          if (mine == nchar_s) {
             if (l == LPP - 1 && jl >= 0 && have) {                                       // haplotype jl is complete
-              a.out[out_base + hcol[jl]] = acc_done;
+              // The read's output row and index come from the LDS stash, the zero of the 64-bit index and the flag's 1 are made right
+              // here (opaque to the compiler, which otherwise keeps each of them, and the flag's address, in a register across the
+              // whole sweep: six registers of a K = 13 wavefront that needs to stay within 128 to run four per SIMD).
+              unsigned lid, zero, one;
+              asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 1" : "=&v"(lid), "=v"(zero), "=v"(one));
+              const uint2 st = stash[lid / LPP];
+              const unsigned long long oi = ((unsigned long long)zero << 32) | (unsigned)(st.x + hcol[jl]);
+              a.out[oi] = acc_done;
               if (RESCUE && acc_done < (T)PHMM_F64_TINY) tiny = true;
-              if (!RESCUE && sizeof(T) == 4 && a.read_flag && acc_done < (T)PHMM_MIN_ACCEPTED) a.read_flag[ridx] = 1u;
+              if (!RESCUE && sizeof(T) == 4 && a.read_flag && acc_done < (T)PHMM_MIN_ACCEPTED) a.read_flag[((unsigned long long)zero << 32) | st.y] = one;
             }
             jl++;
             const T y0 = y0s[jl];
@@ -928,11 +985,15 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
         any_b = any_next;
       }
       t += U;
+      hs_cur += U;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(o1n));     // the loads issued for the step behind the last one (see DistRegs::keep)
     dq.keep();
 #ifdef PHMM_TIMING
-    if (lane == 0) { const unsigned long long tm2 = __builtin_amdgcn_s_memtime(); atomicAdd(&g_phmm_t[0], 1ull); atomicAdd(&g_phmm_t[1], tm1 - tm0); atomicAdd(&g_phmm_t[2], tm2 - tm1); atomicAdd(&g_phmm_t[3], tmA - tm0); atomicAdd(&g_phmm_t[4], tmB - tmA); atomicAdd(&g_phmm_t[5], tmC - tmB); atomicAdd(&g_phmm_t[6], tm1 - tmC); }
+    if (lane == 0) { const unsigned long long tm2 = __builtin_amdgcn_s_memtime(); atomicAdd(&g_phmm_t[0], 1ull); atomicAdd(&g_phmm_t[1], tm1 - tm0); atomicAdd(&g_phmm_t[2], tm2 - tm1); atomicAdd(&g_phmm_t[3], tmA - tm0); atomicAdd(&g_phmm_t[4], tmB - tmA); atomicAdd(&g_phmm_t[5], tmC - tmB); atomicAdd(&g_phmm_t[6], tm1 - tmC); const unsigned long long tw1 = wall_clock64(); atomicAdd(&g_phmm_t[7], tw1 - tw0); atomicMin(&g_phmm_w[0], tw0); atomicMax(&g_phmm_w[1], tw0); atomicMin(&g_phmm_w[2], tw1); atomicMax(&g_phmm_w[3], tw1);
+      unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      const unsigned key = ((xcc & 7u) << 12) | (((hw >> 8) & 0xFFu) << 4) | (((hw >> 6) & 3u) << 2) | ((hw >> 4) & 3u);   // xcc : se,sh,cu : pipe : simd  -> simd in the low 2 bits
+      atomicAdd(&g_phmm_simd_n[key & 32767u], 1u); atomicAdd(&g_phmm_simd_t[key & 32767u], tw1 - tw0); }
 #endif
     return __any(tiny);
   }
@@ -999,8 +1060,15 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   return __any(tiny);
 }
 
-template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false>
-__global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, uint32_t n_work) {
+// Four wavefronts per SIMD (128 registers) is what the five-operation sweep wants up to K = 13 (its loop takes 8 K + 16); the
+// prologue's batched loads would take a few more if the compiler were not told to stay within that.
+template <typename T, int K, int XF> constexpr int phmm_min_waves() { return (sizeof(T) == 4 && XF == 5 && K <= 13) ? 4 : 1; }
+template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false, int W = 1>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(phmm_min_waves<T, K, XF>()))) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, uint32_t n_work) {
+  if constexpr (W > 1) {
+    phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED, W>(a, work_base, blockIdx.x * W + (threadIdx.x >> 6));
+    return;
+  }
   if (RESCUE && a.job_count) {
     // the number of jobs is only known on the device (phmm_rescue_plan); the grid is capped on the host and every wavefront
     // walks the job array with the grid's stride, so a class with nothing to do costs a few hundred empty wavefronts instead
@@ -1024,11 +1092,12 @@ __global__ __launch_bounds__(64) void phmm_kernel(PhmmArgs<T> a, uint32_t work_b
   }
 }
 
-template <typename T, bool STRICT, bool RESCUE, int XF = 0>
+template <typename T, bool STRICT, bool RESCUE, int XF = 0, int W = 1>
 hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st, bool striped = false,
                   uint32_t grid_cap = PHMM_RESCUE_GRID) {
   if (n_work == 0) return hipSuccess;
-  dim3 grid(RESCUE && a.job_count ? (n_work < grid_cap ? n_work : grid_cap) : n_work), block(64);
+  if (W > 1 && (striped || n_work % W != 0)) return hipErrorInvalidValue;
+  dim3 grid(RESCUE && a.job_count ? (n_work < grid_cap ? n_work : grid_cap) : n_work / W), block(64 * W);
   if (striped) {      // reads of 1024 bases and more: 64 lanes x 16 rows per stripe, the generic column
     if (K != 16 || lpp != 64 || XF != 0) return hipErrorInvalidValue;
     size_t lds = phmm_lds_bytes(16, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, 64, false, true);
@@ -1038,9 +1107,9 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
   }
 #define ACCG_CASE(KK, LL)                                                                                     \
   case KK: {                                                                                                  \
-    size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT, KK)); \
+    size_t lds = phmm_lds_bytes(KK, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, LL, phmm_is_compact((int)sizeof(T), STRICT, KK), false, W); \
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;                                                     \
-    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE, XF>), grid, block, lds, st, a, work_base, n_work); \
+    hipLaunchKernelGGL((phmm_kernel<T, KK, LL, STRICT, RESCUE, XF, false, W>), grid, block, lds, st, a, work_base, n_work); \
   } break;
 #ifdef ACCG_PHMM_DEV_SUBSET      // development builds: only the configs[1] kernels (seconds instead of minutes to compile)
   if (lpp == 8 && K == 13) {

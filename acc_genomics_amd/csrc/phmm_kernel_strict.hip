@@ -2,11 +2,11 @@
 // kernels for reads of 1024 bases and more, and the fp32 dispatcher.
 #include "phmm_kernel_impl.h"
 namespace accg {
-hipError_t phmm_launch_f32_fast(int K, int lpp, int form, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s);
-hipError_t phmm_launch_f32(int K, int lpp, bool strict, int form, bool striped, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s) {
+hipError_t phmm_launch_f32_fast(int K, int lpp, int form, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s, int wg);
+hipError_t phmm_launch_f32(int K, int lpp, bool strict, int form, bool striped, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s, int wg) {
   if (striped) return strict ? launch<float, true, false>(K, lpp, a, wb, n, s, true) : launch<float, false, false>(K, lpp, a, wb, n, s, true);
   if (strict) return launch<float, true, false>(K, lpp, a, wb, n, s);
-  return phmm_launch_f32_fast(K, lpp, form, a, wb, n, s);
+  return phmm_launch_f32_fast(K, lpp, form, a, wb, n, s, wg);    // (strict launches run a pair's two items as two independent wavefronts)
 }
 
 // (lanes per read, rows per lane) for a read of `len` bases; K = 0: longer than the kernels support

@@ -25,7 +25,7 @@ with A.Context(0) as ctx:
     wall = (time.perf_counter() - t0) / steps * 1e3
     k = b.time(0, warmup=0, iters=steps, fp32_pass_only=True)
     w = b.time(0, warmup=0, iters=steps)
-    print("%s c1: wall %.4f ms/step, events whole pass %.4f, fp32 kernel alone %.4f, gap %.1f us, %.0f GCUPS" % (tag, wall, w, k, (wall - k) * 1e3, b.cells / wall / 1e6))
+    print("%s c1: wall %.4f ms/step, events whole pass %.4f, fp32 kernel alone %.4f, gap %.1f us, %.0f GCUPS, jobs %d" % (tag, wall, w, k, (wall - k) * 1e3, b.cells / wall / 1e6, b.jobs))
     b.close()
     rng = synth.rng_for(3)
     ser = []
