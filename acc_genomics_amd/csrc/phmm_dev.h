@@ -35,9 +35,12 @@ constexpr bool phmm_is_compact(int elem_bytes, bool strict, int K = 1) { return 
 // (+ 64 bytes at its end: {output row, read index} of the wavefront's up to eight reads, which only the off-the-hot-path code of the
 // sweep needs -- held there they take no registers in the sweep)
 constexpr size_t PHMM_STASH_BYTES = 64;
+// stream region: [pad so that entry lpp-1 is 16-byte aligned: < 16][lpp-1 leading entries][stream_cap][lpp + 20 drain entries, copied in
+// 16-byte units: + 16]
+constexpr size_t PHMM_STREAM_SLACK = 24 + 16 + 16 + 8;
 constexpr size_t phmm_wave_area_bytes(int elem_bytes, int stream_cap, int haps_cap, int lpp = 16, bool striped = false) {
   return phmm_align16((size_t)(haps_cap + 1) * elem_bytes) + phmm_align16((size_t)(2 * haps_cap + 3) * 4) +
-         phmm_align16((size_t)2 * lpp + stream_cap + 24) + (striped ? phmm_align16((size_t)2 * elem_bytes * (stream_cap + 2 * lpp + 24)) : 0) +
+         phmm_align16((size_t)2 * lpp + stream_cap + PHMM_STREAM_SLACK) + (striped ? phmm_align16((size_t)2 * elem_bytes * (stream_cap + 2 * lpp + 24)) : 0) +
          PHMM_STASH_BYTES;
 }
 // wg = wavefronts per workgroup: 1, or 2 that hold the SAME reads against different runs of haplotypes and share one dist table
@@ -70,7 +73,21 @@ struct PhmmTables {
   T init;          // INITIAL_CONSTANT 2^120 | 2^1020  Context.h:109,149
 };
 
-struct PhmmHapDesc { uint32_t off, len, col, id; };   // offset and length of the bases in hblob, column in the region's output row, global hap index
+struct PhmmHapDesc { uint32_t off, len, col, id; };
+// Streams laid out at batch creation (phmm_host.cpp) for the kernels that do not build theirs: one per run of haplotypes,
+// [marker][base codes of haplotype 0][marker][...]...[marker][zeros], marker = nchar, codes A C G T N = 0..4; PhmmWork::pad_[0] = its
+// offset in 16-byte units, pad_[1] = its length up to and including the last marker.  Zeros behind it: at least PHMM_STREAM_TAIL.
+constexpr uint32_t PHMM_STREAM_TAIL = 64 + 20 + 16;
+// Per flat row of a read's wavefront slot, written by phmm_prepare_rows at the start of every pass for the five-operation sweep
+// (three arrays of 16-byte records): what the sweep's registers and dist table hold for that row, so that a job's prologue is straight
+// loads -- no table lookups, no divisions, no selects.  A read that runs on LPP lanes x K rows has LPP * K records, clones of row 0
+// included, in the order the lanes load them: flat row f = lane * K + k at row0[read] + k * LPP + lane (for a given k the lanes
+// of a read fetch LPP consecutive records).  shape[read] = K | LPP << 8, 0 for a read whose wavefront does not run that sweep.
+//   coef = {a, b, pYY, cx}: a = (pMX[r] pGM[r+1]) / pMM[r+1], b = (pMY[r] pGM[r+1]) / pMM[r+1] (0 for the last row),
+//                           cx = (pXX[r] pMX[r-1]) / pMX[r] (0 for the first row); a clone: {0, 0, 1, 0}, the last clone's b = (1 pGM[1]) / pMM[1]
+//   dist = dist(r, A / C / G / T) x pMM[r]; a clone: 0
+//   misc = {dist(r, N) x pMM[r], pMX[r], 0, 0}; a clone: 0
+struct PhmmRowRecs { float4* coef; float4* dist; float4* misc; const uint32_t* row0; const uint32_t* shape; };   // offset and length of the bases in hblob, column in the region's output row, global hap index
 
 constexpr uint32_t PHMM_RESCUE_GRID_DEFAULT = 4096;
 template <typename T>
@@ -96,7 +113,14 @@ struct PhmmArgs {
   int nchar;                  // 4 or 5 slabs in the dist table
   int stream_cap, haps_cap;   // LDS capacities of this launch (entries / haplotypes per job)
   int lds_min;                // host side only: ask for at least this much dynamic LDS (pins the resident wavefronts per CU)
+  uint32_t* zero_words;       // fp32 pass: block 0 of every launch zeroes these n_zero words (rescue job counts, redo counts, the counter of
+  int n_zero;                 //   rescued pairs) -- the previous pass is through with them, this pass's planner comes after the sweep (nullable)
+  int fair;                   // assembly sweep: 1 = a wavefront lowers its issue priority as it advances (see phmm_job), 0 = never
+  PhmmRowRecs rec;            // five-operation sweep: per-row records (phmm_prepare_rows) ...
+  const uint8_t* streams;     // ... and the streams laid out at batch creation
 };
+// one block per read: fills PhmmArgs::rec for reads [0, n_reads); state (nullable): words to zero on the way
+hipError_t phmm_prepare_rows_launch(const PhmmArgs<float>& a, uint32_t n_reads, uint32_t* state, uint32_t state_words, hipStream_t s);
 
 // ---- fp64 rescue planning (device side, no host round trip) -----------------------------------------
 // Reads that underflowed in fp32 against at least one haplotype are regrouped into new wavefront jobs so that
@@ -130,7 +154,7 @@ struct PhmmPlanArgs {
   const uint32_t* sorted_reads;   // per region: its reads by descending length (global ids), at [read0, read0 + n_reads)
   const SeqRef* rd;
   const uint32_t* rd_out;
-  const uint32_t* read_flag;      // written by the fp32 pass
+  uint32_t* read_flag;            // set by the fp32 pass; the planner clears the flags it has read (the next pass starts clean without a memset)
   PhmmWork* jobs;                 // the classes' job arrays back to back: class c at [class_off[c], class_off[c + 1])
   uint32_t* counts;               // jobs written per class
   uint32_t* flagged;              // scratch, one slot per read

@@ -256,6 +256,13 @@ struct accg_phmm_batch {
   std::vector<Region> regions;
   std::vector<SeqRef> rd, hp;
   std::vector<uint32_t> rd_out, hp_local, hap_ids;
+  std::vector<uint32_t> rd_row0; // per read: index of its first record in the per-row records of the five-operation sweep
+  std::vector<uint32_t> rd_shape; // per read: K | LPP << 8 of the wavefront it runs in, 0 if that one does not run the five-operation sweep
+  std::vector<const uint8_t*> hp_ptr;   // per haplotype: its bases in the caller's blob (valid during accg_phmm_batch_create only)
+  std::vector<uint8_t> streams;  // the haplotype streams of all runs, laid out for the kernels that copy theirs in (phmm_dev.h: PHMM_STREAM_TAIL)
+  std::vector<uint32_t> chunk_stream16, chunk_stream_len;   // per run (index into chunks_dev): offset in 16-byte units / length
+  uint64_t n_rows = 0;           // read bases in all = per-row records
+  bool any_form5 = false;        // some launch runs the five-operation sweep: phmm_prepare_rows runs at the start of a fast pass
   std::vector<uint8_t> rd_form;  // per read: the cheapest form of the fast sweep it passes the range tests of: 5, 6 or 7 (phmm_dev.h)
   std::vector<PhmmWork> work;
   std::vector<KLaunch> launches;
@@ -269,6 +276,9 @@ struct accg_phmm_batch {
   DevBuf<uint32_t> d_rd_out, d_hp_local;
   DevBuf<PhmmHapDesc> d_hap_desc;   // hap_ids with the haplotype's descriptor next to each id
   DevBuf<PhmmWork> d_work;
+  DevBuf<uint32_t> d_rd_row0, d_rd_shape;
+  DevBuf<uint8_t> d_streams;
+  DevBuf<float4> d_rec_coef, d_rec_dist, d_rec_misc;
   DevBuf<float> d_out;
   DevBuf<double> d_out64;
   // device-side rescue planning
@@ -330,7 +340,7 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
   }
   return n;
 }
-int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, bool& has_n) {
+int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, bool& has_n, std::vector<const uint8_t*>& ptrs) {
   if (bytes < 4) return ACCG_ERR_BAD_WIRE;
   int32_t n; memcpy(&n, p, 4);
   if (n < 0) return ACCG_ERR_BAD_WIRE;
@@ -346,6 +356,7 @@ int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<Se
       has_n |= p[pos + k] == 'N';
     }
     refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
+    ptrs.push_back(p + pos);
     pos += (size_t)len;
   }
   return n;
@@ -445,6 +456,17 @@ void partition(accg_phmm_batch& b) {
       (Q.form == 5 && !Q.striped ? n_form5 : n_other) += (uint64_t)r.n_haps;
     }
   }
+  // per-row records of the five-operation sweep: LPP * K per read of a wavefront that runs it (phmm_dev.h: PhmmRowRecs)
+  for (const auto& gr : groups)
+    for (const Group& Q : gr)
+      if (Q.form == 5 && !Q.striped && Q.lpp * Q.K > 16)
+        for (int g = 0; g < PHMM_GROUPS; g++)
+          if (Q.read[g] != PHMM_NO_READ) b.rd_shape[Q.read[g]] = (uint32_t)Q.K | ((uint32_t)Q.lpp << 8);
+  for (size_t i = 0; i < b.rd.size(); i++) {
+    b.rd_row0[i] = (uint32_t)b.n_rows;
+    b.n_rows += (uint64_t)(b.rd_shape[i] & 255u) * (uint64_t)(b.rd_shape[i] >> 8);
+  }
+  b.rd_row0[b.rd.size()] = (uint32_t)b.n_rows;
   int K_dom = 1, lpp_dom = 16, n_classes = 0;
   for (int li = 0; li < 4; li++)
     for (int k = 1; k <= PHMM_MAX_K; k++) {
@@ -576,6 +598,20 @@ void partition(accg_phmm_batch& b) {
       ids0.push_back((uint32_t)b.hap_ids.size());
       b.chunks_dev.push_back({(uint32_t)b.hap_ids.size(), run.second});
       for (uint32_t k = 0; k < run.second; k++) b.hap_ids.push_back(r.hap0 + run.first + k);
+      {   // the run's stream: [marker][codes] per haplotype, a last marker, zeros (phmm_dev.h)
+        b.chunk_stream16.push_back((uint32_t)(b.streams.size() / 16));
+        b.chunk_stream_len.push_back(lens[c]);
+        const size_t at = b.streams.size();
+        b.streams.resize(at + (lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16, 0);
+        size_t w_ = at;
+        for (uint32_t k = 0; k < run.second; k++) {
+          const SeqRef& h = b.hp[r.hap0 + run.first + k];
+          b.streams[w_++] = (uint8_t)nchar;
+          const uint8_t* src = b.hp_ptr[r.hap0 + run.first + k];
+          for (uint32_t x = 0; x < h.len; x++) { const uint8_t ch = src[x]; b.streams[w_++] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+        }
+        b.streams[w_++] = (uint8_t)nchar;
+      }
       b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((lens[c] + 63) / 64 * 64));
       b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)run.second);
     }
@@ -592,13 +628,17 @@ void partition(accg_phmm_batch& b) {
       // reads that run in the reference's operation order, and only where it buys occupancy.  (cap_all / hmax_all: the LDS caps so far
       // -- a launch's own caps are only known at the end; this one decision may come out differently for the first regions of a batch.)
       const bool pair = best_pairs && Q.form == 5 && !Q.striped && Q.lpp * Q.K > 16 && pairs_pay(Q.K, nchar, (int)cap_all, (int)hmax_all, Q.lpp);
+      const uint32_t chunk0 = b.regions_dev[ri].chunk0;
       for (size_t c = 0; c < runs.size(); c += pair ? 2 : 1) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
+        w.pad_[0] = b.chunk_stream16[chunk0 + c]; w.pad_[1] = b.chunk_stream_len[chunk0 + c];
         PhmmWork w2 = w;
         uint32_t len = lens[c];
         if (pair) {
-          if (c + 1 < runs.size()) { w2.hap_off = ids0[c + 1]; w2.n_haps = runs[c + 1].second; len = std::max(len, lens[c + 1]); }
-          else { w2.hap_off = 0; w2.n_haps = 0; }
+          if (c + 1 < runs.size()) {
+            w2.hap_off = ids0[c + 1]; w2.n_haps = runs[c + 1].second; len = std::max(len, lens[c + 1]);
+            w2.pad_[0] = b.chunk_stream16[chunk0 + c + 1]; w2.pad_[1] = b.chunk_stream_len[chunk0 + c + 1];
+          } else { w2.hap_off = 0; w2.n_haps = 0; w2.pad_[0] = w2.pad_[1] = 0; }
         }
         const uint64_t stripes = Q.striped ? (b.rd[Q.read[0]].len + 1024) / 1024 : 1;
         jobs.push_back({w, w2, Q.K, Q.lpp, Q.form, Q.striped, pair ? 2 : 1, stripes * (uint64_t)(len + 45) * (uint64_t)(8 * Q.K + 10), len});
@@ -620,6 +660,7 @@ void partition(accg_phmm_batch& b) {
     b.work.push_back(jobs[i].w);
     if (jobs[i].wg == 2) b.work.push_back(jobs[i].w2);
     L.n_work += (uint32_t)jobs[i].wg;
+    b.any_form5 |= jobs[i].form == 5 && !jobs[i].striped && jobs[i].lpp * jobs[i].K > 16;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
     L.haps_cap = std::max(L.haps_cap, (int)std::max(jobs[i].w.n_haps, jobs[i].wg == 2 ? jobs[i].w2.n_haps : 0u));
   }
@@ -640,13 +681,24 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   a.read_flag = b.d_state.p;
   a.nchar = b.has_n ? 5 : 4; a.stream_cap = 0; a.haps_cap = 0; a.job_count = nullptr; a.lds_min = 0;
   a.job_map = nullptr; a.redo_count = nullptr; a.redo_list = nullptr; a.is_redo = 0;
+  a.rec = PhmmRowRecs{b.d_rec_coef.p, b.d_rec_dist.p, b.d_rec_misc.p, b.d_rd_row0.p, b.d_rd_shape.p};
+  a.streams = b.d_streams.p;
+  a.fair = 0; a.zero_words = nullptr; a.n_zero = 0;
   return a;
 }
 
 int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
-  ACCG_HIP(hipMemsetAsync(b->d_state.p, 0, state_words(*b) * sizeof(uint32_t), b->ctx->stream));   // flags, counts, n_rescued
-  if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
+  // A pass needs no memset: the read flags are cleared by the planner as it reads them, the rescue job counts and the counter of
+  // rescued pairs by block 0 of every sweep launch (the previous pass is through with them, this pass's planner runs behind the sweep),
+  // and batch creation left all of them at zero.  ACCG_PHMM_PREPARE_EACH_PASS=1: the per-row records of the five-operation sweep
+  // (phmm_prepare_rows; normally written once, at batch creation, like the streams) are rewritten at the start of every pass.
+  static const bool each_pass = [] { const char* e = getenv("ACCG_PHMM_PREPARE_EACH_PASS"); return e && e[0] == '1'; }();
+  if (each_pass && mode != ACCG_PHMM_STRICT && b->any_form5 && b->n_rows)
+    ACCG_HIP(phmm_prepare_rows_launch(a, (uint32_t)b->rd.size(), nullptr, 0, b->ctx->stream));
+  a.zero_words = b->d_state.p + state_counts(*b);
+  a.n_zero = (int)(state_words(*b) - state_counts(*b));
+  if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
   const bool fork = b->launches.size() > 1;          // several rows-per-lane classes: run them side by side
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
   int rr = 0;
@@ -661,6 +713,11 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
     const int wpc = b->force_wpc > 0 ? std::min(b->force_wpc, natural) : b->force_wpc < 0 ? natural
                     : strict_l ? std::max(natural / 4 * 4, std::min(natural, 4)) : pinned_wpc(natural);
     a.lds_min = (int)((160 * 1024 / std::max(wpc / wg, 1)) / 512 * 512);     // per workgroup
+    // Priority steps (phmm_job): for a launch that is about one round of jobs on the chip's slots, where all wavefronts of a SIMD start
+    // together and the arbiter's oldest-first rule makes them finish far apart (configs[1]: 0.279 -> 0.259 ms); with several rounds the
+    // slots refill as they empty and the steps only cost (a 128-region configs[3] shard: + 2 %).  ACCG_PHMM_FAIR: 0 = never, n = thresholds n.
+    static const int fair_knob = [] { const char* e = getenv("ACCG_PHMM_FAIR"); return e ? atoi(e) : 3; }();
+    a.fair = (uint64_t)l.n_work <= 2ull * (uint64_t)b->ctx->n_cu * (uint64_t)std::max(wpc, 1) ? fair_knob : 0;
     // Reads of at most 15 bases take the reference's operation order in fast mode too: their log10 is close to 0, where the
     // reference's float `log10f(x) - log10f(2^120)` has a granularity of 3.8e-6 absolute, so a one-ulp difference in x can show
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
@@ -732,7 +789,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
     int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd, b->rd_form);
     if (nr < 0) return nr;
-    int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp, b->has_n);
+    int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp, b->has_n, b->hp_ptr);
     if (nh < 0) return nh;
     r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;
     uint64_t rsum = 0, hsum = 0;
@@ -750,6 +807,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     roff += reads_bytes[i]; hoff += haps_bytes[i];
   }
   b->algo_bytes = roff + hoff + 4 * b->pairs;   // blobs in, one float per pair out
+  b->rd_row0.assign(b->rd.size() + 1, 0); b->rd_shape.assign(b->rd.size(), 0);   // filled by partition()
   const auto tp0 = std::chrono::steady_clock::now();
   partition(*b);
   const auto tp1 = std::chrono::steady_clock::now();
@@ -768,8 +826,11 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const size_t o_rblob = take(roff + 16), o_hblob = take(hoff + 16), o_rd = take(vbytes(b->rd)), o_hp = take(vbytes(b->hp)),
                o_rd_out = take(vbytes(b->rd_out)), o_hp_local = take(vbytes(b->hp_local)), o_hap_ids = take(b->hap_ids.size() * sizeof(PhmmHapDesc)),
                o_work = take(vbytes(b->work)), o_regions = take(vbytes(b->regions_dev)), o_chunks = take(vbytes(b->chunks_dev)),
-               o_sorted = take(vbytes(b->sorted_reads));
+               o_sorted = take(vbytes(b->sorted_reads)), o_row0 = take(vbytes(b->rd_row0)), o_shape = take(vbytes(b->rd_shape)), o_streams = take(b->streams.size() + 16);
   const size_t upload_bytes = off;
+  if (b->n_rows >= (1ull << 32)) return ACCG_ERR_TOO_LONG;
+  const size_t n_rec = (size_t)b->n_rows + 1;
+  const size_t o_rec_coef = take(n_rec * sizeof(float4)), o_rec_dist = take(n_rec * sizeof(float4)), o_rec_misc = take(n_rec * sizeof(float4));
   const size_t o_flagged = take((b->rd.size() + 1) * sizeof(uint32_t));
   const size_t o_jobs = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(PhmmWork));
   const size_t o_redo = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(uint32_t));
@@ -785,6 +846,8 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_hap_desc.place(base, o_hap_ids, b->hap_ids.size()); b->d_work.place(base, o_work, b->work.size());
   b->d_regions.place(base, o_regions, b->regions_dev.size()); b->d_chunks.place(base, o_chunks, b->chunks_dev.size());
   b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
+  b->d_rd_row0.place(base, o_row0, b->rd_row0.size()); b->d_rd_shape.place(base, o_shape, b->rd_shape.size()); b->d_streams.place(base, o_streams, b->streams.size() + 16);
+  b->d_rec_coef.place(base, o_rec_coef, n_rec); b->d_rec_dist.place(base, o_rec_dist, n_rec); b->d_rec_misc.place(base, o_rec_misc, n_rec);
   b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
   b->d_rescue_jobs.place(base, o_jobs, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
   b->d_redo.place(base, o_redo, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
@@ -810,8 +873,15 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     for (size_t i = 0; i < b->hap_ids.size(); i++) { const uint32_t g = b->hap_ids[i]; hd[i] = PhmmHapDesc{b->hp[g].off, b->hp[g].len, b->hp_local[g], g}; }
   }
   put(o_work, b->work); put(o_regions, b->regions_dev); put(o_chunks, b->chunks_dev); put(o_sorted, b->sorted_reads);
+  put(o_row0, b->rd_row0); put(o_shape, b->rd_shape); put(o_streams, b->streams);
+  memset(stage + o_streams + b->streams.size(), 0, 16);
+  b->hp_ptr.clear(); b->hp_ptr.shrink_to_fit();            // the caller's blobs are not ours beyond this call
   if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
   ACCG_HIP(hipMemsetAsync(base + o_out64, 0, (o_out - o_out64) + (b->pairs + 1) * sizeof(float), s));   // out64, state, out
+  if (b->any_form5 && b->n_rows) {       // the per-row records of the five-operation sweep (phmm_dev.h: PhmmRowRecs), from the uploaded reads
+    const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, ctx->tab_f);
+    ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), nullptr, 0, s));
+  }
   ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
   if (getenv("ACCG_TRACE")) fprintf(stderr, "accg_phmm_batch_create: partition %.0f us, arena + upload %.0f us\n", std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count());
   sync_on_error.dismiss();

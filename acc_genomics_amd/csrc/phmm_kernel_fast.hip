@@ -14,4 +14,9 @@ hipError_t phmm_launch_f32_fast(int K, int lpp, int form, const PhmmArgs<float>&
 #endif
   return e;
 }
+hipError_t phmm_prepare_rows_launch(const PhmmArgs<float>& a, uint32_t n_reads, uint32_t* state, uint32_t state_words, hipStream_t s) {
+  if (n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(phmm_prepare_rows, dim3(n_reads), dim3(128), 0, s, a, n_reads, state, state_words);
+  return hipGetLastError();
+}
 }  // namespace accg

@@ -643,6 +643,8 @@ template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool
 __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_base, const uint32_t job, const bool count_rescued = true) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool X6 = XF == 6, X5 = XF == 5;     // six- / five-operation form of the fp32 fast sweep (0: seven operations)
+  // the five-operation fp32 pass runs on prepared inputs: per-row records (phmm_prepare_rows) and streams laid out at batch creation
+  constexpr bool PRE = X5 && !RESCUE && !STRIPED && sizeof(T) == 4;
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT, K) && !STRIPED;
   constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
@@ -652,10 +654,11 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB + (W > 1 ? wave * (int)phmm_wave_area_bytes((int)sizeof(T), a.stream_cap, a.haps_cap, LPP, STRIPED) : 0));
   uint32_t* hcol = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(y0s) + phmm_align16(sizeof(T) * (a.haps_cap + 1)));
   uint32_t* bpos = hcol + a.haps_cap + 1;
-  uint8_t* stream = reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4);
+  // (entry LPP - 1, where the first haplotype's bubble sits, is 16-byte aligned: a stream laid out at batch creation is copied in in 16-byte units)
+  uint8_t* stream = reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4) + ((16 - (LPP - 1) % 16) % 16);
   uint2* stash = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y0s) + phmm_wave_area_bytes((int)sizeof(T), a.stream_cap, a.haps_cap, LPP, STRIPED) - PHMM_STASH_BYTES);
   // striped reads (more rows than a wavefront holds): what the last lane hands "to the right", per stream position, for the next stripe
-  T* carry_a = reinterpret_cast<T*>(stream + phmm_align16((size_t)2 * LPP + a.stream_cap + 24));
+  T* carry_a = reinterpret_cast<T*>(reinterpret_cast<uint8_t*>(hcol) + phmm_align16((size_t)(2 * a.haps_cap + 3) * 4) + phmm_align16((size_t)2 * LPP + a.stream_cap + PHMM_STREAM_SLACK));
   T* carry_x = carry_a + (a.stream_cap + 2 * LPP + 24);
 
   const int lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -674,7 +677,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   const bool have = ridx != PHMM_NO_READ;
   SeqRef rr = {0u, 0u};
   uint32_t out_base = 0;
-  if (have) { rr = a.rd[ridx]; out_base = a.rd_out[ridx]; }
+  uint32_t rec0 = 0;               // PRE: the read's first row in the per-row records
+  if (have) { rr = a.rd[ridx]; out_base = a.rd_out[ridx]; if constexpr (PRE) rec0 = a.rec.row0[ridx]; }
   if (g < NG && l == LPP - 1) stash[g] = make_uint2(out_base, ridx);      // for the off-the-hot-path code of the assembly sweep
 
   // ---- haplotype stream: [15 pad] bubble hap0 bubble hap1 ... bubble(terminal) [pad] ----------
@@ -683,6 +687,25 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   int pos = 0, n_haps = 0;
   unsigned n_flag = 0;
   for (int i = lane; i < LPP - 1; i += 64) stream[i] = 0;
+  if constexpr (PRE) {
+    // The stream as laid out at batch creation, 16 bytes per lane and round: one memory latency (built here, from the haplotypes'
+    // bases, it was four dependent levels of loads: 18 000 cycles of a job whose sweep takes 335 000 at four wavefronts per SIMD).
+    const uint32_t s_off16 = __builtin_amdgcn_readfirstlane(wp->pad_[0]), s_len = __builtin_amdgcn_readfirstlane(wp->pad_[1]);
+    const uint4* src = reinterpret_cast<const uint4*>(a.streams) + s_off16;
+    uint4* dst = reinterpret_cast<uint4*>(stream + LPP - 1);
+    const int n16 = (int)((s_len + LPP + 20 + 15) / 16);
+    uint32_t col_l = 0, hlen_l = 0;
+    if (lane < n_list) { const PhmmHapDesc h_ = a.hap_desc[hap_off + lane]; col_l = h_.col; hlen_l = h_.len; }
+    for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+    // bubble positions = exclusive prefix sums of (length + 1) over the job's haplotypes, one per lane
+    const unsigned v = lane < n_list ? hlen_l + 1u : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    if (lane < n_list) { bpos[lane] = incl - v; y0s[lane] = a.tab.init / (T)(int)hlen_l; hcol[lane] = col_l; }   // baseline_impl.cpp:63
+    pos = (int)__builtin_amdgcn_readlane(incl, 63);
+    n_haps = n_list;
+  } else {
   // the haplotypes' descriptors, one per lane (a job lists at most PHMM_HAPS_MAX = 48): two latencies for all of them instead
   // of two per haplotype
   uint32_t col_l = 0, hoff_l = 0, hlen_l = 0;
@@ -717,12 +740,13 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     pos += (int)hr.len + 1;
     n_haps++;
   }
+  }
   if (RESCUE) {
     if (n_haps == 0) return false;
     if (lane == 0 && count_rescued) atomicAdd(a.n_rescued, (unsigned long long)n_flag);
   }
   if (lane == 0) { bpos[n_haps] = pos; bpos[n_haps + 1] = 0x7FFFFFFF; y0s[n_haps] = T(0); hcol[n_haps] = 0; }
-  for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = i == 0 ? (uint8_t)a.nchar : (uint8_t)0;   // terminal bubble + drain + prefetch slack
+  if (!PRE) for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = i == 0 ? (uint8_t)a.nchar : (uint8_t)0;   // terminal bubble + drain + prefetch slack
   const int t_end = __builtin_amdgcn_readfirstlane(pos + LPP);         // the last lane passes the terminal bubble at pos+LPP-1
 #ifdef PHMM_TIMING
   __builtin_amdgcn_s_waitcnt(0);
@@ -748,6 +772,74 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   const int roff = stripe == 0 ? 0 : rows0 + (stripe - 1) * SROWS;   // read row (0-based) of the stripe's first non-clone flat row
   s.npad = pad - l * K;                     // clones are the first `pad` flat rows
   typedef typename Vec16<T>::type V;
+#ifdef PHMM_TIMING
+  unsigned long long tmB = tmA, tmC = tmA;
+#endif
+  if constexpr (PRE) {
+    // Prepared rows: the K coefficient records of the lane's rows (their components ARE the sweep's registers), the chain
+    // coefficient of the row behind them, pMX of the last one and the first row's clone coefficient, then the dist records into
+    // the table -- one memory latency behind the read's descriptor, no table lookups, no divisions (phmm_prepare_rows did them
+    // once per read and pass; here they cost every job 20 000 cycles of gathers and every CU 2 700 gather instructions at once).
+    // (record of local row k of this lane: rec0 + k * LPP + l; clones of row 0 have records of their own)
+    float4 co[K], cn = make_float4(0.f, 0.f, 0.f, 0.f), ml = cn;
+#pragma unroll
+    for (int k = 0; k < K; k++) co[k] = cn;
+    if (have) {
+      const float4* rc = a.rec.coef + rec0 + l;
+#pragma unroll
+      for (int k = 0; k < K; k++) co[k] = rc[k * LPP];
+      if (l < LPP - 1) cn = rc[1];                          // row 0 of the lane to the right
+      ml = a.rec.misc[rec0 + (K - 1) * LPP + l];            // pMX of this lane's last row
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      s.M[k] = T(0); s.X[k] = T(0); s.Y[k] = T(0);
+      s.pXX[k] = co[k].z;                                    // pYY (a clone: 1, it keeps its Ys = INIT/H)
+      s.pMX[k] = co[k].w;                                    // chain coefficient of Xs
+      s.pMY[k] = T(0);
+      if (k + 1 < K) { s.pGM[k + 1] = co[k].x; s.pMM[k + 1] = co[k].y; }     // what this row's Xs / Ys enter the term for the row below with
+    }
+    s.pGM[0] = T(0); s.pMM[0] = T(0);
+    s.nGM = co[K - 1].x; s.nMM = co[K - 1].y;
+    s.xl = ml.y;
+    s.nXX = cn.w;
+    s.nMX = l == LPP - 1 ? T(0) : T(1);
+    s.gclone = T(0);
+#ifdef PHMM_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    tmB = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      float4 dd[VN];
+      float dn5[VN];
+#pragma unroll
+      for (int e = 0; e < VN; e++) {
+        const int k = q * VN + e;
+        dd[e] = make_float4(0.f, 0.f, 0.f, 0.f); dn5[e] = 0.f;
+        if (k < K && have) {
+          dd[e] = a.rec.dist[rec0 + k * LPP + l];
+          if (a.nchar > 4) dn5[e] = a.rec.misc[rec0 + k * LPP + l].x;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        if (c >= a.nchar) break;
+        if (W > 1 && (c % W) != wave) continue;       // the workgroup's wavefronts hold the same reads: each writes its share of the slabs
+        V v;
+#pragma unroll
+        for (int e = 0; e < VN; e++) v[e] = c == 0 ? dd[e].x : c == 1 ? dd[e].y : c == 2 ? dd[e].z : c == 3 ? dd[e].w : dn5[e];
+        constexpr int TS = phmm_tail_stride(K, (int)sizeof(T));
+        if (q < K / VN || TS == 16) *reinterpret_cast<V*>(tab + c * SLAB + q * 1024 + lane * 16) = v;
+        else if (TS == 8) { typedef float V2 __attribute__((ext_vector_type(2))); *reinterpret_cast<V2*>(tab + c * SLAB + q * 1024 + lane * 8) = V2{(float)v[0], (float)v[1]}; }
+        else *reinterpret_cast<T*>(tab + c * SLAB + q * 1024 + lane * TS) = v[0];
+      }
+    }
+#ifdef PHMM_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    tmC = __builtin_amdgcn_s_memtime();
+#endif
+  } else {
   // Two batches of loads for the lane's K rows and row 0 of the lane to the right (index K): the five bytes of every row, then
   // the table entries they select -- two memory latencies per job.  (With the loads inside "is this a read row?" branches,
   // one row at a time, a job spent 26 dependent latencies here: a quarter of a wavefront's time on configs[1].)  Rows that are
@@ -776,7 +868,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   }
 #ifdef PHMM_TIMING
   __builtin_amdgcn_s_waitcnt(0);
-  const unsigned long long tmB = __builtin_amdgcn_s_memtime();
+  tmB = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll
   for (int q = 0; q < QT; q++) {
@@ -820,7 +912,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   }
 #ifdef PHMM_TIMING
   __builtin_amdgcn_s_waitcnt(0);
-  const unsigned long long tmC = __builtin_amdgcn_s_memtime();
+  tmC = __builtin_amdgcn_s_memtime();
 #endif
   {
     const int r = roff + (l + 1) * K - pad; // row 0 of the lane to the right (of the next stripe, for the last lane of a stripe that has one)
@@ -879,6 +971,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
       s.pMX[k] = s.pMX[k] != T(0) ? (s.pXX[k] * s.pMX[k - 1]) / s.pMX[k] : T(0);
     }
   }
+  }
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
   if constexpr (W > 1) {
     __syncthreads();                                        // the other wavefront's slabs of the table
@@ -930,7 +1023,20 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
     unsigned hs_cur = hs_a;            // LDS address of this lane's stream byte of step t: the ONE register the stream takes in the sweep
+    // Issue priority.  The SIMD's arbiter serves the oldest wavefront first: of four wavefronts that start a sweep together the oldest
+    // runs at its own full rate and finishes at 0.4 of the time the youngest needs (measured, -DPHMM_TIMING: 132 against 318 us on
+    // configs[1]), and what is left runs two, then one to a SIMD, at a third of the issue rate.  So a wavefront starts at priority 3 and
+    // steps down at every quarter of its sweep: whoever is ahead yields, and the four stay within a quarter of each other.
+    // (a.fair picks the three thresholds, in 32nds of the sweep)
+    const int f1 = a.fair == 1 ? 8 : a.fair == 2 ? 16 : a.fair == 3 ? 20 : a.fair == 4 ? 24 : a.fair == 5 ? 28 : 16;
+    const int f2 = a.fair == 1 ? 16 : a.fair == 2 ? 24 : a.fair == 3 ? 26 : a.fair == 4 ? 28 : a.fair == 5 ? 30 : 22;
+    const int f3 = a.fair == 1 ? 24 : a.fair == 2 ? 28 : a.fair == 3 ? 30 : a.fair == 4 ? 30 : a.fair == 5 ? 31 : 28;
+    const int q1 = a.fair ? (t_stop * f1 / 32 + U - 1) / U * U : -1, q2 = a.fair ? (t_stop * f2 / 32 + U - 1) / U * U : -1, q3 = a.fair ? (t_stop * f3 / 32 + U - 1) / U * U : -1;
+    if (a.fair) __builtin_amdgcn_s_setprio(3);
     while (t < t_stop) {
+      if (__builtin_expect(t == q1, 0)) __builtin_amdgcn_s_setprio(2);
+      if (__builtin_expect(t == q2, 0)) __builtin_amdgcn_s_setprio(1);
+      if (__builtin_expect(t == q3, 0)) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int u = 0; u < U; u++) {
         // the stream byte issued one step ago has landed: address of the next step's slab and its bubble flag, next byte on its way
@@ -1065,6 +1171,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 template <typename T, int K, int XF> constexpr int phmm_min_waves() { return (sizeof(T) == 4 && XF == 5 && K <= 13) ? 4 : 1; }
 template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false, int W = 1>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(phmm_min_waves<T, K, XF>()))) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, uint32_t n_work) {
+  if (!RESCUE && a.zero_words && blockIdx.x == 0)          // see PhmmArgs::zero_words
+    for (int i = threadIdx.x; i < a.n_zero; i += 64 * W) a.zero_words[i] = 0u;
   if constexpr (W > 1) {
     phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED, W>(a, work_base, blockIdx.x * W + (threadIdx.x >> 6));
     return;
@@ -1142,6 +1250,56 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
 #undef ACCG_CASE
 }
 
+// Per-row records of the five-operation sweep (PhmmRowRecs, phmm_dev.h): one block of 64 threads per read, once per pass.  The
+// arithmetic -- which float is multiplied with and divided by which, in which order -- is the prologue's own of the kernels that do
+// not use the records (phmm_job, the X5 block), so both give the same bits (oracle model: orc_phmm_forward_f32_fma5).
+__global__ __launch_bounds__(128) void phmm_prepare_rows(PhmmArgs<float> a, uint32_t n_reads, uint32_t* state, uint32_t state_words) {
+  if (state) for (uint32_t i = blockIdx.x * 128u + threadIdx.x; i < state_words; i += gridDim.x * 128u) state[i] = 0u;
+  const uint32_t rid = blockIdx.x;
+  if (rid >= n_reads) return;
+  const uint32_t shape = a.rec.shape[rid];
+  if (shape == 0) return;                                   // this read's wavefront runs another form of the sweep
+  const int K = (int)(shape & 255u), LPP = (int)(shape >> 8), SROWS = K * LPP;
+  const SeqRef rr = a.rd[rid];
+  const int R = (int)rr.len, pad = SROWS - R;               // rows are right-aligned: the first `pad` flat rows are clones of row 0
+  const uint8_t* rb = a.rblob + rr.off;
+  const uint32_t row0 = a.rec.row0[rid];
+  // One thread per flat row, everything it needs loaded by itself: the row's five bytes, the next row's three qualities and the
+  // previous row's insertion quality in one round trip, the table entries they select in a second (no exchange between threads).
+  for (int f = threadIdx.x; f < SROWS; f += 128) {
+    const int l = f / K, k = f - l * K, r = f - pad;
+    const uint32_t at = row0 + (uint32_t)(k * LPP + l);
+    auto tri = [](int x, int y) { const int lo = x < y ? x : y, hi = x < y ? y : x; return ((hi * (hi + 1)) >> 1) + lo; };
+    if (r < 0) {                                            // a clone of row 0; the last one hands Y = INIT/H to the first row
+      float bclone = 0.f;
+      if (r == -1 && R > 0) {
+        const float m1 = a.tab.m2m[tri(rb[2 * R] & 127, rb[3 * R] & 127)], g1 = a.tab.omph[rb[4 * R] & 127];
+        bclone = m1 != 0.f ? (1.0f * g1) / m1 : 0.f;
+      }
+      a.rec.coef[at] = make_float4(0.f, bclone, 1.f, 0.f);
+      a.rec.dist[at] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.rec.misc[at] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const int rn = r + 1 < R ? r + 1 : r, rp = r > 0 ? r - 1 : r;
+    const int base = char_index(rb[r]), qq = rb[R + r] & 127, qi = rb[2 * R + r] & 127, qd = rb[3 * R + r] & 127, qc = rb[4 * R + r] & 127;
+    const int ni = rb[2 * R + rn] & 127, nd = rb[3 * R + rn] & 127, nc = rb[4 * R + rn] & 127, pi = rb[2 * R + rp] & 127;
+    const float pMM = a.tab.m2m[tri(qi, qd)], pMX = a.tab.ph[qi], pXX = a.tab.ph[qc], pMY = a.tab.ph[qd];
+    const float nMM = a.tab.m2m[tri(ni, nd)], nGM = a.tab.omph[nc], qMX = a.tab.ph[pi];
+    const float dM = a.tab.omph[qq] * pMM, dX = a.tab.phd3[qq] * pMM;      // baseline_impl.cpp:79-83, times the row's pMM
+    float ca = 0.f, cb = 0.f, cx = 0.f;
+    if (r + 1 < R) {
+      ca = nMM != 0.f ? (pMX * nGM) / nMM : 0.f;
+      cb = nMM != 0.f ? (pMY * nGM) / nMM : 0.f;
+    }
+    if (r > 0) cx = pMX != 0.f ? (pXX * qMX) / pMX : 0.f;
+    a.rec.coef[at] = make_float4(ca, cb, pXX, cx);
+    a.rec.dist[at] = make_float4(base == CH_N || base == CH_A ? dM : dX, base == CH_N || base == CH_C ? dM : dX,
+                                 base == CH_N || base == CH_G ? dM : dX, base == CH_N || base == CH_T ? dM : dX);
+    a.rec.misc[at] = make_float4(dM, pMX, 0.f, 0.f);
+  }
+}
+
 // One workgroup per region: list the reads with an fp32 result below MIN_ACCEPTED (host_type.h:21), in the
 // region's length order, cut the list into wavefront-sized groups and emit (group x haplotype run) jobs into the
 // job array of the group's class.  The fp64 kernel then drops the haplotypes none of the group's reads needs.
@@ -1160,6 +1318,7 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
     if (i < R.n_reads) {
       rid = p.sorted_reads[R.read0 + i];
       f = p.read_flag[rid] != 0;
+      if (f) p.read_flag[rid] = 0u;            // read and cleared: the next pass's sweep finds its flags at zero
     }
     const unsigned long long m = __ballot(f);
     if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
