@@ -1005,6 +1005,21 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     // two branches per step, and issue slots are what the sweep is short of.)
     unsigned any_b, any_next;   // does any lane meet a bubble this step / the next one
     const unsigned nchar_s = __builtin_amdgcn_readfirstlane((int)a.nchar);
+    constexpr int U = 8;
+    const int t_stop = (t_end + U - 1) / U * U;
+    // Issue priority.  The SIMD's arbiter serves the oldest wavefront first: of four wavefronts that start a sweep together the oldest
+    // runs at its own full rate and finishes at 0.4 of the time the youngest needs (measured, -DPHMM_TIMING: 132 against 318 us on
+    // configs[1]), and what is left runs two, then one to a SIMD, at a third of the issue rate.  So a wavefront starts at priority 3 and
+    // steps down at every quarter of its sweep: whoever is ahead yields, and the four stay within a quarter of each other.
+    // (a.fair picks the three thresholds, in 32nds of the sweep)
+    const int f1 = a.fair == 1 ? 8 : a.fair == 2 ? 16 : a.fair == 3 ? 20 : a.fair == 4 ? 24 : a.fair == 5 ? 28 : 16;
+    const int f2 = a.fair == 1 ? 16 : a.fair == 2 ? 24 : a.fair == 3 ? 26 : a.fair == 4 ? 28 : a.fair == 5 ? 30 : 22;
+    const int f3 = a.fair == 1 ? 24 : a.fair == 2 ? 28 : a.fair == 3 ? 30 : a.fair == 4 ? 30 : a.fair == 5 ? 31 : 28;
+    const int q1 = a.fair ? (t_stop * f1 / 32 + U - 1) / U * U : -1, q2 = a.fair ? (t_stop * f2 / 32 + U - 1) / U * U : -1, q3 = a.fair ? (t_stop * f3 / 32 + U - 1) / U * U : -1;
+    if (a.fair) __builtin_amdgcn_s_setprio(3);
+    // (all of this in front of the first hand-issued load: between those loads and the loop there must be no compiled code, which
+    // takes their destination registers for written -- the empty statement pins the three thresholds, as scalars, to this point)
+    asm volatile("" ::"s"(q1), "s"(q2), "s"(q3));
     {
       // step 0's values (its slab index read and awaited on the spot), then the steady-state order: U, L0 .. L(QT-1)
       unsigned b0;
@@ -1017,22 +1032,10 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
     // U steps per loop iteration, in one straight line (a taken branch costs a wave some 30 cycles: with a loop back edge, a
     // bubble test and a "next bubble" test per step the single-step form of this loop lost 15 %).  The trip count is rounded up:
     // the steps past t_end run over the stream's padding after the terminal bubble and write nothing.
-    constexpr int U = 8;
-    const int t_stop = (t_end + U - 1) / U * U;
 #ifdef PHMM_TIMING
     const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
     unsigned hs_cur = hs_a;            // LDS address of this lane's stream byte of step t: the ONE register the stream takes in the sweep
-    // Issue priority.  The SIMD's arbiter serves the oldest wavefront first: of four wavefronts that start a sweep together the oldest
-    // runs at its own full rate and finishes at 0.4 of the time the youngest needs (measured, -DPHMM_TIMING: 132 against 318 us on
-    // configs[1]), and what is left runs two, then one to a SIMD, at a third of the issue rate.  So a wavefront starts at priority 3 and
-    // steps down at every quarter of its sweep: whoever is ahead yields, and the four stay within a quarter of each other.
-    // (a.fair picks the three thresholds, in 32nds of the sweep)
-    const int f1 = a.fair == 1 ? 8 : a.fair == 2 ? 16 : a.fair == 3 ? 20 : a.fair == 4 ? 24 : a.fair == 5 ? 28 : 16;
-    const int f2 = a.fair == 1 ? 16 : a.fair == 2 ? 24 : a.fair == 3 ? 26 : a.fair == 4 ? 28 : a.fair == 5 ? 30 : 22;
-    const int f3 = a.fair == 1 ? 24 : a.fair == 2 ? 28 : a.fair == 3 ? 30 : a.fair == 4 ? 30 : a.fair == 5 ? 31 : 28;
-    const int q1 = a.fair ? (t_stop * f1 / 32 + U - 1) / U * U : -1, q2 = a.fair ? (t_stop * f2 / 32 + U - 1) / U * U : -1, q3 = a.fair ? (t_stop * f3 / 32 + U - 1) / U * U : -1;
-    if (a.fair) __builtin_amdgcn_s_setprio(3);
     while (t < t_stop) {
       if (__builtin_expect(t == q1, 0)) __builtin_amdgcn_s_setprio(2);
       if (__builtin_expect(t == q2, 0)) __builtin_amdgcn_s_setprio(1);
