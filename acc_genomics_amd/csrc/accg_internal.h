@@ -64,6 +64,9 @@ struct accg_ctx {
   // host thread at a time (it owns one stream), so the staging needs no lock.
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
+  // a slot of an accg_phmm_ring: batch creation does not wait for its upload (the staging block is the slot's own and is not
+  // touched again before the slot's results have been fetched)
+  bool async_create = false;
   // Independent kernels of one pass (one launch per rows-per-lane class) are spread over these streams, forked from and
   // joined back to `stream`: queued on one stream each launch would wait for the previous one's last wavefront.
   static constexpr int N_AUX = 4;

@@ -408,6 +408,9 @@ void chunk_region(const accg_phmm_batch& b, const Region& r, uint64_t budget, st
 // chip (one prologue + 15-step fill per job against the quantisation of jobs over slots); e.g.
 // configs[1] comes out as 4096 jobs of 4 haplotypes = exactly one job per slot at 16 waves per CU.
 void partition(accg_phmm_batch& b) {
+  static const bool trace_p = getenv("ACCG_TRACE") != nullptr;
+  const auto tpa = std::chrono::steady_clock::now();
+  auto tpb = tpa, tpc = tpa, tpd = tpa;
   const int nchar = b.has_n ? 5 : 4;
   const int n_cu = std::max(b.ctx->n_cu, 1);
   // read groups per region (one group = the reads of one wavefront), by descending read length so that they need the same K
@@ -475,6 +478,7 @@ void partition(accg_phmm_batch& b) {
     }
   n_classes = std::max(n_classes, 1);
 
+  tpb = std::chrono::steady_clock::now();
   // candidate budgets: multiples of the most common haplotype length, plus a geometric ladder
   std::vector<uint64_t> cand;
   if (!b.hp.empty()) {
@@ -497,28 +501,24 @@ void partition(accg_phmm_batch& b) {
   // Jobs take few distinct costs (chunk length x rows per lane), so the longest-first list schedule is simulated on
   // histograms: job costs in descending order, slot loads as load -> number of slots.  Assigning k equal jobs to the k
   // least-loaded slots of one bucket is what the sequential rule does one job at a time.
-  std::map<double, uint64_t, std::greater<double>> hist;
-  std::map<double, uint64_t> loads;
-  std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
-  uint64_t seen_sig = 0;
-  bool last_pairs_pay = false;
   // The jobs of the dominant class go in pairs (one workgroup of two wavefronts sharing the dist table) when that buys occupancy;
   // the schedule is then simulated on pairs and workgroup slots.  Whether it does depends on the stream length, i.e. on the budget:
-  // each candidate is simulated singly first and, if pairs would pay at its caps, again in pairs.
-  for (int pass = 0; pass < 2 * (int)cand.size(); pass++) {
-    const uint64_t budget = cand[pass / 2];
-    const bool sim_pairs = pass & 1;
-    if (sim_pairs && !(n_form5 >= n_other && last_pairs_pay)) continue;
-    hist.clear();
+  // each candidate is simulated singly and, if pairs would pay at its caps, again in pairs.  The candidates are independent of each
+  // other: they are evaluated on the host threads this process may use, and the first best one in candidate order is taken.
+  const bool dom5 = n_form5 >= n_other;
+  struct Eval { double span = -1; bool pays = false; };
+  auto evaluate = [&](uint64_t budget, bool sim_pairs) -> Eval {
+    std::map<double, uint64_t, std::greater<double>> hist;
+    std::map<double, uint64_t> loads;
+    std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
     uint32_t cap = 0, hmax = 1;
-    uint64_t n_jobs = 0, sig = 1469598103934665603ull;
+    uint64_t n_jobs = 0;
     for (size_t ri = 0; ri < b.regions.size(); ri++) {
       if (groups[ri].empty()) continue;
       runs.clear(); lens.clear();
       chunk_region(b, b.regions[ri], budget, runs, lens);
-      for (uint32_t len : lens) { cap = std::max(cap, len); sig = (sig ^ len) * 1099511628211ull; }
+      for (uint32_t len : lens) cap = std::max(cap, len);
       for (const auto& run : runs) hmax = std::max(hmax, run.second);
-      sig = (sig ^ 0xFFFFFFFFull) * 1099511628211ull;
       int lastK = -1; uint64_t mult = 0;                       // groups are sorted by length: equal K come in runs
       // (pairs: a workgroup of two wavefronts lasts as long as the longer of its two runs)
       auto flush = [&]() {
@@ -535,53 +535,61 @@ void partition(accg_phmm_batch& b) {
       flush();
       n_jobs += (uint64_t)groups[ri].size() * (sim_pairs ? (lens.size() + 1) / 2 : lens.size());
     }
-    if (n_jobs == 0) break;
-    sig = (sig ^ (sim_pairs ? 2u : 1u)) * 1099511628211ull;
-    if (!sim_pairs) last_pairs_pay = lpp_dom * K_dom > 16 && pairs_pay(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom);
-    if (sig == seen_sig) continue;                             // same chunking as the previous candidate
-    seen_sig = sig;
+    Eval ev;
+    if (n_jobs == 0) return ev;
+    ev.pays = lpp_dom * K_dom > 16 && pairs_pay(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom);
     // Resident wavefronts per CU: what registers and LDS allow, or fewer on purpose.  tools/ubench2.hip: the instruction mix of the
     // sweep issues at 1.32 / 1.34 / 1.26 / 1.07 ns per wave-instruction per SIMD with 2 / 3 / 4 / 8 resident wavefronts and at
     // 5 ns for a wavefront that has its SIMD to itself -- a third wavefront per SIMD buys nothing, an odd one per CU unbalances the
     // SIMDs and a lone one at the tail is slow.  So the occupancy is one of 8, 16 or 32 per CU (the launches ask for as much LDS
     // as it takes to get exactly that), and a slot's speed is its SIMD's rate divided by the wavefronts sharing it.
-    const bool dom5 = n_form5 >= n_other;
     const int wpc_max = waves_per_cu(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom, false, dom5 ? 5 : 6, sim_pairs ? 2 : 1);
-    {
-      const int wpc = force_wpc > 0 ? std::min(force_wpc, wpc_max) : force_wpc < 0 ? wpc_max : pinned_wpc(wpc_max);
-      const int w = std::max(1, wpc / 4);
-      const int slots = n_cu * wpc / (sim_pairs ? 2 : 1);
-      loads.clear();
-      loads[0.0] = (uint64_t)slots;
-      for (const auto& hc : hist) {
-        uint64_t left = hc.second;
-        while (left) {
-          auto lo = loads.begin();
-          const uint64_t k = std::min(left, lo->second);
-          const double nl = lo->first + hc.first;
-          if (k == lo->second) loads.erase(lo); else lo->second -= k;
-          loads[nl] += k;
-          left -= k;
-        }
+    const int wpc = force_wpc > 0 ? std::min(force_wpc, wpc_max) : force_wpc < 0 ? wpc_max : pinned_wpc(wpc_max);
+    const int w = std::max(1, wpc / 4);
+    const int slots = std::max(1, n_cu * wpc / (sim_pairs ? 2 : 1));
+    loads[0.0] = (uint64_t)slots;
+    for (const auto& hc : hist) {
+      uint64_t left = hc.second;
+      while (left) {
+        auto lo = loads.begin();
+        const uint64_t k = std::min(left, lo->second);
+        const double nl = lo->first + hc.first;
+        if (k == lo->second) loads.erase(lo); else lo->second -= k;
+        loads[nl] += k;
+        left -= k;
       }
-      // (five-operation column, three VOP3 in five: 1.46 measured at 2 wavefronts per SIMD, VOP3 1.6 / 1.37 / 1.2 / 1.03 and
-      // VOP2 1.3 / 1.32 / 1.14 / 1.0 ns at 2 / 3 / 4 / 8)
-      const double rate = dom5 ? (w >= 8 ? 1.02 : w >= 4 ? 1.17 : w == 3 ? 1.35 : w == 2 ? 1.46 : 5.0)
-                               : (w >= 8 ? 1.07 : w >= 4 ? 1.26 : w == 3 ? 1.34 : w == 2 ? 1.32 : 5.0);
-      double span = loads.rbegin()->first * rate * w;
-      // the hardware dispatcher is not an ideal list scheduler, and a slot that runs out of jobs early leaves its SIMD partner
-      // alone at a quarter of the issue rate: a mild preference for several jobs per slot
-      // ... and every (lanes, K) class is a launch of its own with a tail of its own, and the rescue pass inherits the chunking: with
-      // the ten classes of a configs[3] mix a 128-region shard ran 18 % faster on jobs a third the size this term used to pick
-      // (2.65 against 3.22 ms with the rescue; 1024 regions: the same choice as before)
-      span *= 1.0 + 0.05 * (double)n_classes * (double)slots / (double)n_jobs;
-      // long streams cost LDS (occupancy of the launches with few rows per lane) and lengthen the tail of every launch: measured
-      // on the configs[3] mix +1 % at 2048 entries and +4.5 % at 4096 against 1300 (tools/sweep_c3.sh)
-      if (cap > 1300) span *= 1.0 + 0.03 * ((double)cap - 1300.0) / 1024.0;
-      if (best_span < 0 || span < best_span) { best_span = span; best_budget = budget; best_pairs = sim_pairs; }
     }
+    // (five-operation column, three VOP3 in five: 1.46 measured at 2 wavefronts per SIMD, VOP3 1.6 / 1.37 / 1.2 / 1.03 and
+    // VOP2 1.3 / 1.32 / 1.14 / 1.0 ns at 2 / 3 / 4 / 8)
+    const double rate = dom5 ? (w >= 8 ? 1.02 : w >= 4 ? 1.17 : w == 3 ? 1.35 : w == 2 ? 1.46 : 5.0)
+                             : (w >= 8 ? 1.07 : w >= 4 ? 1.26 : w == 3 ? 1.34 : w == 2 ? 1.32 : 5.0);
+    double span = loads.rbegin()->first * rate * w;
+    // the hardware dispatcher is not an ideal list scheduler, and a slot that runs out of jobs early leaves its SIMD partner
+    // alone at a quarter of the issue rate: a mild preference for several jobs per slot
+    // ... and every (lanes, K) class is a launch of its own with a tail of its own, and the rescue pass inherits the chunking: with
+    // the ten classes of a configs[3] mix a 128-region shard ran 18 % faster on jobs a third the size this term used to pick
+    // (2.65 against 3.22 ms with the rescue; 1024 regions: the same choice as before)
+    span *= 1.0 + 0.05 * (double)n_classes * (double)slots / (double)n_jobs;
+    // long streams cost LDS (occupancy of the launches with few rows per lane) and lengthen the tail of every launch: measured
+    // on the configs[3] mix +1 % at 2048 entries and +4.5 % at 4096 against 1300 (tools/sweep_c3.sh)
+    if (cap > 1300) span *= 1.0 + 0.03 * ((double)cap - 1300.0) / 1024.0;
+    ev.span = span;
+    return ev;
+  };
+  std::vector<double> span1(cand.size(), -1.0), span2(cand.size(), -1.0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (cand.size() * b.regions.size() >= 512)
+  for (int ci = 0; ci < (int)cand.size(); ci++) {
+    const Eval e1 = evaluate(cand[ci], false);
+    span1[ci] = e1.span;
+    if (dom5 && e1.pays) span2[ci] = evaluate(cand[ci], true).span;
   }
+  for (size_t ci = 0; ci < cand.size(); ci++)
+    for (int pr = 0; pr < 2; pr++) {
+      const double span = pr ? span2[ci] : span1[ci];
+      if (span >= 0 && (best_span < 0 || span < best_span)) { best_span = span; best_budget = cand[ci]; best_pairs = pr != 0; }
+    }
 
+  tpc = std::chrono::steady_clock::now();
   struct Job { PhmmWork w, w2; int K, lpp, form; bool striped; int wg; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   uint32_t cap_all = 0, hmax_all = 1;
@@ -645,11 +653,22 @@ void partition(accg_phmm_batch& b) {
       }
     }
   }
+  tpd = std::chrono::steady_clock::now();
   // one launch per K; inside a launch the longest jobs go first so the tail is short
-  std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
+  // (sorted through an index: a Job is 120 bytes, the order is decided by a few of them)
+  std::vector<uint32_t> order(jobs.size());
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t xi, uint32_t yi) {
+    const Job &x = jobs[xi], &y = jobs[yi];
     return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.form != y.form ? x.form < y.form : x.wg != y.wg ? x.wg > y.wg
                                                                                                                                 : x.cost > y.cost;
   });
+  {
+    std::vector<Job> sorted;
+    sorted.reserve(jobs.size());
+    for (uint32_t i : order) sorted.push_back(jobs[i]);
+    jobs.swap(sorted);
+  }
   b.work.clear();
   b.work.reserve(jobs.size() * 2);
   for (size_t i = 0; i < jobs.size(); i++) {
@@ -663,6 +682,11 @@ void partition(accg_phmm_batch& b) {
     b.any_form5 |= jobs[i].form == 5 && !jobs[i].striped && jobs[i].lpp * jobs[i].K > 16;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
     L.haps_cap = std::max(L.haps_cap, (int)std::max(jobs[i].w.n_haps, jobs[i].wg == 2 ? jobs[i].w2.n_haps : 0u));
+  }
+  if (trace_p) {
+    auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+    fprintf(stderr, "partition: groups %.0f us, budget search %.0f us, jobs + streams %.0f us, sort + flatten %.0f us (%zu jobs)\n", us(tpa, tpb), us(tpb, tpc), us(tpc, tpd),
+            us(tpd, std::chrono::steady_clock::now()), jobs.size());
   }
 }
 
@@ -780,17 +804,32 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   std::unique_ptr<accg_phmm_batch> b(new accg_phmm_batch);
   SyncOnError sync_on_error(ctx->stream);
   b->ctx = ctx;
+  const auto tparse0 = std::chrono::steady_clock::now();
   uint64_t roff = 0, hoff = 0;
   for (int i = 0; i < n_regions; i++) { roff += reads_bytes[i]; hoff += haps_bytes[i]; }
   if (roff >= (1ull << 32) || hoff >= (1ull << 32)) return ACCG_ERR_TOO_LONG;   // 32-bit blob offsets
-  roff = hoff = 0;
+  // Regions are parsed (lengths, base validation, the range tests of the sweep's forms) independently of each other, on the host
+  // threads this process may use when there are enough of them, and merged in order.
+  struct Parsed { std::vector<SeqRef> rd, hp; std::vector<uint8_t> form; std::vector<const uint8_t*> hp_ptr; bool has_n = false; int nr = 0, nh = 0; };
+  std::vector<Parsed> parsed((size_t)n_regions);
+  std::vector<uint64_t> roffs((size_t)n_regions + 1, 0), hoffs((size_t)n_regions + 1, 0);
+  for (int i = 0; i < n_regions; i++) { roffs[i + 1] = roffs[i] + reads_bytes[i]; hoffs[i + 1] = hoffs[i] + haps_bytes[i]; }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (n_regions >= 8)
   for (int i = 0; i < n_regions; i++) {
+    Parsed& P = parsed[i];
+    P.nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roffs[i], P.rd, P.form);
+    if (P.nr >= 0) P.nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoffs[i], P.hp, P.has_n, P.hp_ptr);
+  }
+  for (int i = 0; i < n_regions; i++) {
+    const Parsed& P = parsed[i];
+    if (P.nr < 0) return P.nr;
+    if (P.nh < 0) return P.nh;
     Region r;
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
-    int nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roff, b->rd, b->rd_form);
-    if (nr < 0) return nr;
-    int nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoff, b->hp, b->has_n, b->hp_ptr);
-    if (nh < 0) return nh;
+    const int nr = P.nr, nh = P.nh;
+    b->rd.insert(b->rd.end(), P.rd.begin(), P.rd.end()); b->rd_form.insert(b->rd_form.end(), P.form.begin(), P.form.end());
+    b->hp.insert(b->hp.end(), P.hp.begin(), P.hp.end()); b->hp_ptr.insert(b->hp_ptr.end(), P.hp_ptr.begin(), P.hp_ptr.end());
+    b->has_n |= P.has_n;
     r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;
     uint64_t rsum = 0, hsum = 0;
     for (int k = 0; k < nr; k++) rsum += b->rd[r.read0 + k].len;
@@ -804,9 +843,11 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     for (int k = 0; k < nh; k++) b->hp_local.push_back((uint32_t)k);
     b->pairs += (uint64_t)nr * nh;
     b->regions.push_back(r);
-    roff += reads_bytes[i]; hoff += haps_bytes[i];
   }
+  parsed.clear();
+  roff = roffs[n_regions]; hoff = hoffs[n_regions];
   b->algo_bytes = roff + hoff + 4 * b->pairs;   // blobs in, one float per pair out
+  if (getenv("ACCG_TRACE")) fprintf(stderr, "accg_phmm_batch_create: parse %.0f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tparse0).count());
   b->rd_row0.assign(b->rd.size() + 1, 0); b->rd_shape.assign(b->rd.size(), 0);   // filled by partition()
   const auto tp0 = std::chrono::steady_clock::now();
   partition(*b);
@@ -882,7 +923,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, ctx->tab_f);
     ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), nullptr, 0, s));
   }
-  ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
+  if (!ctx->async_create) ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
   if (getenv("ACCG_TRACE")) fprintf(stderr, "accg_phmm_batch_create: partition %.0f us, arena + upload %.0f us\n", std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count());
   sync_on_error.dismiss();
   *out = b.release();
@@ -1013,6 +1054,38 @@ extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, in
   return accg_phmm_batch_time2(b, mode, 0, warmup, iters, ms_per_run);
 }
 
+namespace {
+// results of a pass in two halves for the ring: the device-to-host copies queued behind the kernels (both result arrays, always),
+// and the host half -- wait, log10 (same libm as the reference) -- when the caller comes for them
+size_t results_stage_bytes(uint64_t pairs) { return (sizeof(unsigned long long) + pairs * sizeof(float) + 7) / 8 * 8 + pairs * sizeof(double) + 64; }
+int results_enqueue(accg_phmm_batch* b) {
+  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
+  void* stage_v = nullptr;
+  ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));      // (sized by the submitter before the upload: no reallocation here)
+  uint8_t* stage = (uint8_t*)stage_v;
+  ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
+  if (n) ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+  return ACCG_OK;
+}
+int results_finish(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* cnt) {
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
+  const uint8_t* stage = (const uint8_t*)b->ctx->h_stage;
+  unsigned long long nresc = 0;
+  memcpy(&nresc, stage, sizeof nresc);
+  const float* raw = (const float*)(stage + sizeof nresc);
+  const double* r64 = (const double*)(stage + head_al);
+  if (out_raw && n) memcpy(out_raw, raw, n * sizeof(float));
+  if (out_log10 && n) {
+    const HostTables& t = host_tables();
+    for (size_t i = 0; i < n; i++)             // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
+      out_log10[i] = raw[i] < PHMM_MIN_ACCEPTED ? log10(r64[i]) - t.log10_init_d : (double)(log10f(raw[i]) - t.log10_init_f);
+  }
+  if (cnt) { cnt->cells = b->cells; cnt->pairs = b->pairs; cnt->kernel_ns = b->last_kernel_ns; cnt->rescued = nresc; }
+  return ACCG_OK;
+}
+}  // namespace
+
 extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* cnt) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
@@ -1103,4 +1176,82 @@ extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t rea
             (unsigned long long)pairs, us(t0, t1), us(t1, t2), kernel_ns / 1e3, us(t2, t3), us(t3, clk::now()));
   }
   return st;
+}
+
+
+// ---- ring of regions in flight ------------------------------------------------------------------------------------------------
+// The one-shot call above is a latency chain: parse and size the jobs, upload, kernels, download, log10 -- the device idles while the
+// host works and the host while the device does.  A ring keeps up to `slots` regions in flight on contexts of their own (stream,
+// device block cache, pinned staging): accg_phmm_ring_submit does the host half of region i and queues its upload, kernels and
+// downloads without waiting; accg_phmm_ring_wait fetches the results of the oldest one -- while region i computes, region i + 1
+// is being parsed and region i - 1 read back.  compute_fpga / FalconPairHMM::computePairhmm keep their blocking signatures on
+// top of accg_phmm_region (pairhmm/host/PairHMMFpga.h:16-20); a caller that owns the loop over active regions uses the ring.
+struct accg_phmm_ring {
+  std::vector<accg_ctx*> ctx;
+  std::vector<accg_phmm_batch*> batch;       // per slot: the region in flight (null: free)
+  uint64_t next_ticket = 0;
+};
+
+extern "C" int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out || slots < 1 || slots > 64) return ACCG_ERR_BAD_ARG;
+  *out = nullptr;
+  std::unique_ptr<accg_phmm_ring> r(new accg_phmm_ring);
+  for (int i = 0; i < slots; i++) {
+    accg_ctx* c = nullptr;
+    const int st = accg_init(ctx->device, &c);
+    if (st != ACCG_OK) { for (accg_ctx* x : r->ctx) accg_shutdown(x); return st; }
+    c->async_create = true;
+    r->ctx.push_back(c);
+  }
+  r->batch.assign((size_t)slots, nullptr);
+  *out = r.release();
+  return ACCG_OK;
+}
+
+extern "C" int accg_phmm_ring_submit(accg_phmm_ring* r, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
+                                     int mode, uint64_t* ticket) {
+  if (!r || !ticket) return ACCG_ERR_BAD_ARG;
+  const size_t slot = (size_t)(r->next_ticket % r->ctx.size());
+  if (r->batch[slot]) return ACCG_ERR_BAD_ARG;                 // the slot's previous region has not been waited for
+  accg_ctx* c = r->ctx[slot];
+  ACCG_HIP(hipSetDevice(c->device));
+  // pinned staging large enough for the upload AND the downloads, before anything is queued (it must not move in between)
+  if (reads_bytes < 4 || haps_bytes < 4) return ACCG_ERR_BAD_WIRE;
+  int32_t nr = 0, nh = 0;
+  memcpy(&nr, reads_ser, 4); memcpy(&nh, haps_ser, 4);
+  if (nr < 0 || nh < 0) return ACCG_ERR_BAD_WIRE;
+  void* stage = nullptr;
+  ACCG_HIP(ctx_stage(c, std::max(results_stage_bytes((uint64_t)nr * (uint64_t)nh), 2 * (reads_bytes + haps_bytes) + ((size_t)1 << 20)), &stage));
+  accg_phmm_batch* b = nullptr;
+  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
+  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
+  int st = accg_phmm_batch_create(c, 1, rs, rb, hs, hb, &b);
+  if (st != ACCG_OK) return st;
+  b->graph_off = true;
+  st = accg_phmm_batch_run(b, mode);
+  if (st == ACCG_OK) st = results_enqueue(b);
+  if (st != ACCG_OK) { accg_phmm_batch_destroy(b); return st; }
+  r->batch[slot] = b;
+  *ticket = r->next_ticket++;
+  return ACCG_OK;
+}
+
+extern "C" int accg_phmm_ring_wait(accg_phmm_ring* r, uint64_t ticket, float* out_raw, double* out_log10, accg_counters* cnt) {
+  if (!r || ticket >= r->next_ticket || ticket + r->ctx.size() < r->next_ticket) return ACCG_ERR_BAD_ARG;
+  const size_t slot = (size_t)(ticket % r->ctx.size());
+  accg_phmm_batch* b = r->batch[slot];
+  if (!b) return ACCG_ERR_BAD_ARG;                            // waited for already
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  const int st = results_finish(b, out_raw, out_log10, cnt);
+  accg_phmm_batch_destroy(b);
+  r->batch[slot] = nullptr;
+  return st;
+}
+
+extern "C" void accg_phmm_ring_destroy(accg_phmm_ring* r) {
+  if (!r) return;
+  for (accg_phmm_batch* b : r->batch) if (b) accg_phmm_batch_destroy(b);
+  for (accg_ctx* c : r->ctx) accg_shutdown(c);
+  delete r;
 }

@@ -1311,8 +1311,17 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
   __shared__ uint32_t s_wave[4];
   const PhmmRegionDev R = p.regions[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_base = 0;
+  // nothing flagged in this region (the usual case for reads that belong to their haplotypes): out after one sweep over the flags
+  __shared__ uint32_t s_any;
+  if (tid == 0) { s_base = 0; s_any = 0; }
   __syncthreads();
+  {
+    uint32_t any = 0;
+    for (uint32_t i = tid; i < R.n_reads; i += 256) any |= p.read_flag[R.read0 + i];
+    if (any) s_any = 1u;
+  }
+  __syncthreads();
+  if (!s_any) return;
   uint32_t* out = p.flagged + R.read0;
   for (uint32_t i0 = 0; i0 < R.n_reads; i0 += 256) {          // ordered compaction, 256 reads at a time
     const uint32_t i = i0 + tid;

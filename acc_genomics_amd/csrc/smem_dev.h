@@ -45,4 +45,10 @@ hipError_t smem_build_ktab(const SmemArgs& a, uint4* ktab, hipStream_t s);
 // persistent wavefronts that take reads from a queue; compact (32-bit) index only; scratch for n_waves x 64 threads
 hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s);
 
+// the -DSMEM_COUNT build of the same kernels (smem_kernel.hip): performed lookups counted into device counters
+hipError_t smem_launch_count(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s);
+hipError_t smem_launch_engine_count(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s);
+// {index sectors (32-byte half-blocks) fetched, prefix-table entries fetched, bwt_extend calls, 0} since the last reset
+hipError_t smem_counts_read(uint64_t out[4], bool reset, hipStream_t s);
+
 }  // namespace accg

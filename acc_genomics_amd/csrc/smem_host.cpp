@@ -168,15 +168,27 @@ extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
   // wavefronts per CU (by an LDS request): at most 24 for the fused kernel (measured best when it needed 63 VGPRs; with the prefix
   // table it needs 86 and 20 fit anyway); the split form picks per kernel (smem_launch).  ACCG_SMEM_WPC overrides, 0 = no limit.
   { const char* e = getenv("ACCG_SMEM_WPC"); a.waves_per_cu = e ? (uint32_t)atoi(e) : (b->d_seg ? 0u : 24u); }
+  // ACCG_SMEM_COUNT=1: the counting build of the same kernels (measurement runs only: accg_smem_debug_counts)
+  static const bool counting = [] { const char* e = getenv("ACCG_SMEM_COUNT"); return e && e[0] == '1'; }();
   if (b->engine_waves) {
     a.queue = b->d_queue;
     ACCG_HIP(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), x->ctx->stream));
-    ACCG_HIP(smem_launch_engine(a, 0, b->n, b->engine_waves, x->ctx->stream));
+    ACCG_HIP(counting ? smem_launch_engine_count(a, 0, b->n, b->engine_waves, x->ctx->stream) : smem_launch_engine(a, 0, b->n, b->engine_waves, x->ctx->stream));
     return ACCG_OK;
   }
   a.queue = nullptr;
   for (uint32_t r0 = 0; r0 < b->n; r0 += b->slice)
-    ACCG_HIP(smem_launch(a, r0, std::min(b->slice, b->n - r0), x->ctx->stream));
+    ACCG_HIP(counting ? smem_launch_count(a, r0, std::min(b->slice, b->n - r0), x->ctx->stream) : smem_launch(a, r0, std::min(b->slice, b->n - r0), x->ctx->stream));
+  return ACCG_OK;
+}
+// Lookups the SMEM kernels really performed since the last call (only under ACCG_SMEM_COUNT=1, else zeros): {32-byte index
+// sectors fetched, prefix-table entries fetched, bwt_extend calls, 0}.  The reference accounts REQUESTED blocks
+// (smem/host/baseline.cpp:28-75); this is what the device fetched.
+extern "C" int accg_smem_debug_counts(accg_ctx* ctx, uint64_t out[4]) {
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  if (!out) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(ctx->device));
+  ACCG_HIP(smem_counts_read(out, true, ctx->stream));
   return ACCG_OK;
 }
 extern "C" int accg_smem_batch_time(accg_smem_batch* b, int warmup, int iters, float* ms_per_run) {

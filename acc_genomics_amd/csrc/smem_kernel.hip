@@ -19,8 +19,39 @@
 #include <algorithm>
 #include "smem_dev.h"
 
+// -DSMEM_COUNT (a second object built from this file, Makefile): the same kernels with three counters -- half-block (32-byte
+// sector) fetches of the index actually performed, prefix-table entries fetched, bwt_extend calls -- so that the roofline of the
+// launch is priced on the lookups the kernel really makes, not on the reference's count of requested blocks.  The exported launchers
+// get a _count suffix; the product build has none of this.
+#ifdef SMEM_COUNT
+#define ACCG_SMEM_SUFFIX(n) n##_count
+#else
+#define ACCG_SMEM_SUFFIX(n) n
+#endif
+
 namespace accg {
+#ifdef SMEM_COUNT
+__device__ unsigned long long g_smem_counts[4];     // sectors fetched, table entries fetched, extend calls, (unused)
+hipError_t smem_counts_read(uint64_t out[4], bool reset, hipStream_t s) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_smem_counts), sizeof h);
+  for (int i = 0; i < 4; i++) out[i] = h[i];
+  if (e == hipSuccess && reset) { const unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_smem_counts), z, sizeof z); }
+  return e;
+}
+#endif
 namespace {
+#ifdef SMEM_COUNT
+// one atomic per wavefront and call site: the lanes that are here together add up first
+__device__ __forceinline__ void smem_count(int which, unsigned n) {      // n is 1 or 2
+  const unsigned long long m = __ballot(1), m2 = __ballot(n == 2u);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&g_smem_counts[which], (unsigned long long)(__popcll(m) + __popcll(m2)));
+}
+#define ACCG_SMEM_COUNT(which, n) smem_count(which, n)
+#else
+#define ACCG_SMEM_COUNT(which, n) ((void)0)
+#endif
 
 constexpr int MIN_SEED_LEN = 19;   // smem/common/common.h:37
 
@@ -98,6 +129,8 @@ __device__ __forceinline__ void occ4_2(const Ctx<uint32_t>& f, uint32_t k, uint3
   const uint4* bk = reinterpret_cast<const uint4*>(f.bwt + ((k >> 6) << 3));
   uint4 h = bk[0], pl = bk[1];
   count_planes(h, pl, k & 63u, tk);
+  ACCG_SMEM_COUNT(0, (k >> 6) != (l >> 6) ? 2u : 1u);
+  ACCG_SMEM_COUNT(2, 1u);
   if ((k >> 6) != (l >> 6)) {
     const uint4* bl = reinterpret_cast<const uint4*>(f.bwt + ((l >> 6) << 3));
     h = bl[0]; pl = bl[1];
@@ -193,6 +226,7 @@ __device__ __forceinline__ bool ktab_code(const Q& q, int x, int len, uint32_t& 
 template <typename IT> __device__ __forceinline__ Intv<IT> ktab_entry(const uint4* tab, int L, uint32_t code);
 template <> __device__ __forceinline__ Intv<uint32_t> ktab_entry<uint32_t>(const uint4* tab, int L, uint32_t code) {
   const uint4 e = tab[smem_ktab_off(L) + (code >> (2 * (SMEM_KTAB_L - L)))];
+  ACCG_SMEM_COUNT(1, 1u);
   Intv<uint32_t> r; r.x0 = e.x; r.x1 = e.y; r.x2 = e.z; r.info = 0;
   return r;
 }
@@ -788,7 +822,7 @@ __global__ __launch_bounds__(256) void smem_ktab_kernel(SmemArgs a, uint4* tab, 
 
 }  // namespace
 
-hipError_t smem_build_ktab(const SmemArgs& a, uint4* ktab, hipStream_t s) {
+hipError_t ACCG_SMEM_SUFFIX(smem_build_ktab)(const SmemArgs& a, uint4* ktab, hipStream_t s) {
   if (!a.compact) return hipErrorInvalidValue;
   for (int L = 1; L <= SMEM_KTAB_L; L++) {
     const uint32_t n = 1u << (2 * L);
@@ -797,13 +831,13 @@ hipError_t smem_build_ktab(const SmemArgs& a, uint4* ktab, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t smem_launch_engine(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s) {
+hipError_t ACCG_SMEM_SUFFIX(smem_launch_engine)(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, uint32_t n_waves, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
   hipLaunchKernelGGL(smem_engine, dim3(n_waves), dim3(64), 0, s, a, read_base, n_reads);
   return hipGetLastError();
 }
 
-hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
+hipError_t ACCG_SMEM_SUFFIX(smem_launch)(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
   const dim3 grid((n_reads + 63) / 64), block(64);
   const size_t row = (size_t)64 * a.read_words * sizeof(uint32_t);

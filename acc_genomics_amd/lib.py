@@ -47,6 +47,10 @@ def load():
     L.accg_device_name.argtypes = [vp, C.c_char_p, sz]
     L.accg_phmm_region.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_region_f64.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.accg_phmm_ring_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.accg_phmm_ring_submit.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.POINTER(C.c_uint64)]
+    L.accg_phmm_ring_wait.argtypes = [vp, C.c_uint64, vp, vp, C.POINTER(Counters)]
+    L.accg_phmm_ring_destroy.argtypes = [vp]
     L.accg_phmm_batch_create.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
     for n in ("accg_phmm_batch_pairs", "accg_phmm_batch_cells", "accg_phmm_batch_algorithmic_bytes", "accg_phmm_batch_jobs"):
         getattr(L, n).restype = C.c_uint64
@@ -94,6 +98,7 @@ def load():
     L.accg_smem_batch_time.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_smem_batch_results.argtypes = [vp, vp, vp]
     L.accg_smem_batch_destroy.argtypes = [vp]
+    L.accg_smem_debug_counts.argtypes = [vp, vp]
     L.accg_bwasw_batch_create.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(vp)]
     L.accg_bwasw_batch_cells.restype = C.c_uint64
     L.accg_bwasw_batch_cells.argtypes = [vp]
@@ -170,6 +175,38 @@ def _phmm_region_f64(self, reads_ser, haps_ser, n_pairs):
 
 
 Context.phmm_region_f64 = _phmm_region_f64
+
+
+class PhmmRing:
+    """Regions in flight (accg_phmm_ring_*): submit() returns a ticket at once, wait(ticket, n_pairs) the region's results."""
+
+    def __init__(self, ctx, slots=4):
+        self.ctx, self.L, self.slots = ctx, ctx.L, slots
+        self.h = C.c_void_p()
+        _check(self.L.accg_phmm_ring_create(ctx.h, slots, C.byref(self.h)))
+
+    def submit(self, reads_ser, haps_ser, mode=ACCG_PHMM_FAST):
+        t = C.c_uint64()
+        _check(self.L.accg_phmm_ring_submit(self.h, reads_ser, len(reads_ser), haps_ser, len(haps_ser), mode, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket, n_pairs, want_log10=True):
+        raw = np.zeros(n_pairs, np.float32)
+        l10 = np.zeros(n_pairs, np.float64) if want_log10 else None
+        cnt = Counters()
+        _check(self.L.accg_phmm_ring_wait(self.h, ticket, raw.ctypes.data, l10.ctypes.data if want_log10 else None, C.byref(cnt)))
+        return raw, l10, cnt
+
+    def close(self):
+        if self.h:
+            self.L.accg_phmm_ring_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class PhmmBatch:

@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (fp32 VALU issue, no FMA double count)
 N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32
-PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8,six-op column in gfx950 assembly>"
+PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8,five-op column in gfx950 assembly,two wavefronts per workgroup sharing the dist table>"
 SMEM_KERNEL_NAME = "smem_kernel<uint32_t>"
 SMEM_SECTOR_PEAK_G = 110.0      # G random 32-byte sectors/s, two dependent sectors per step (tools/ubench_random.hip)
 
@@ -501,18 +501,49 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
     out = {"c1": {"ms_per_call": t1 * 1e3, "value": cells / t1 / 1e9, "unit": "GCUPS",
                   "what": "one configs[1] region (2048 x 32) per call, median of 5 calls"}}
     if n_c3 > 0:
+        import acc_genomics_amd as A
         regs = [c3_region(k) for k in range(n_c3)]
         ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
         c3_cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs)
-        ts = []
-        for rep in range(4):
-            t0 = time.perf_counter()
+
+        def med(f, reps=4):
+            ts = []
+            for rep in range(reps):
+                t0 = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts[1:]))
+
+        def blocking():
             for a, b, m in ser:
                 ctx.phmm_region(a, b, m, mode)
-            ts.append(time.perf_counter() - t0)
-        t3 = float(np.median(ts[1:]))
-        out["c3_slice"] = {"regions": n_c3, "ms_total": t3 * 1e3, "ms_per_region": t3 / n_c3 * 1e3, "value": c3_cells / t3 / 1e9, "unit": "GCUPS",
-                           "what": "the first %d configs[3] regions (128 reads x 16 haplotypes each), one blocking call per region, median of 3 passes" % n_c3}
+
+        def ring(slots=4):
+            pend = []
+            for a, b, m in ser:
+                if len(pend) == slots:
+                    t, mm = pend.pop(0)
+                    rg.wait(t, mm)
+                pend.append((rg.submit(a, b, mode), m))
+            for t, mm in pend:
+                rg.wait(t, mm)
+
+        def one_batch():
+            with A.PhmmBatch(ctx, [(a, b) for a, b, _ in ser]) as bt:
+                bt.run(mode)
+                bt.results()
+
+        t_block = med(blocking)
+        with A.PhmmRing(ctx, 4) as rg:
+            t_ring = med(ring)
+        t_batch = med(one_batch)
+        what = "the first %d configs[3] regions (128 reads x 16 haplotypes each), median of 3 passes" % n_c3
+        out["c3_slice"] = {"regions": n_c3, "ms_total": t_block * 1e3, "ms_per_region": t_block / n_c3 * 1e3, "value": c3_cells / t_block / 1e9,
+                           "unit": "GCUPS", "what": "one blocking accg_phmm_region call per region; " + what}
+        out["c3_slice_ring"] = {"regions": n_c3, "slots": 4, "ms_total": t_ring * 1e3, "value": c3_cells / t_ring / 1e9, "unit": "GCUPS",
+                                "what": "accg_phmm_ring_submit / _wait, four regions in flight, one caller thread; " + what}
+        out["c3_slice_one_batch"] = {"regions": n_c3, "ms_total": t_batch * 1e3, "value": c3_cells / t_batch / 1e9, "unit": "GCUPS",
+                                     "what": "all regions handed over at once: accg_phmm_batch_create + _run + _results; " + what}
     out["note"] = "host memory to host memory, parse + job sizing + upload + kernels + download + log10 all inside; not the headline value"
     return out
 
@@ -681,7 +712,7 @@ def main():
         flops = 12.0 * batch.cells / (k_ms * 1e-3)
         tj = traffic().get("phmm_c1", {})            # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
         insts = tj.get("valu_insts_per_launch")
-        issue = valu_issue(insts, k_ms, ubench_ns=1.32, waves_per_simd=2) if insts else None
+        issue = valu_issue(insts, k_ms, ubench_ns=1.17, waves_per_simd=4) if insts else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": tj.get("hbm_bytes_per_launch"), "kernel": PHMM_KERNEL_NAME, "kernel_ms": k_ms,
                 "kernel_ms_how": "mean over %d whole passes run right behind the timed region, HIP events around the fp32 sweep launch "

@@ -84,6 +84,19 @@ int accg_ctx_trim(accg_ctx* ctx);
 int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
                      size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* counters);
 
+/* Regions in flight.  accg_phmm_region is a latency chain (the caller waits); a caller that owns the loop over active regions keeps up
+ * to `slots` of them in flight instead: accg_phmm_ring_submit does the host half of a region (parse, job sizing, staging) and queues
+ * its upload, kernels and downloads on a stream of the slot's own without waiting; accg_phmm_ring_wait returns the results of a
+ * submitted region -- while region i computes, region i + 1 is parsed and region i - 1 read back.  Tickets count up from 0; at most
+ * `slots` may be outstanding (submit fails with ACCG_ERR_BAD_ARG when the slot of ticket - slots has not been waited for).  Same
+ * results, bit for bit, as accg_phmm_region.  The blobs may be reused as soon as submit returns.  One thread at a time per ring. */
+typedef struct accg_phmm_ring accg_phmm_ring;
+int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out);
+int accg_phmm_ring_submit(accg_phmm_ring* ring, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
+                          int mode, uint64_t* ticket);
+int accg_phmm_ring_wait(accg_phmm_ring* ring, uint64_t ticket, float* out_raw, double* out_log10, accg_counters* counters);
+void accg_phmm_ring_destroy(accg_phmm_ring* ring);
+
 /* The same region entirely in fp64 (compute_fp_avxd, avx_impl.h:6; use_double, FalconPairHMM.cpp:82): raw x 2^1020. */
 int accg_phmm_region_f64(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
                          double* out_raw64);
@@ -185,6 +198,10 @@ int accg_smem_batch_run(accg_smem_batch* b);
 int accg_smem_batch_time(accg_smem_batch* b, int warmup, int iters, float* ms_per_run);
 int accg_smem_batch_results(accg_smem_batch* b, void* mem_output, int32_t* mem_num);
 void accg_smem_batch_destroy(accg_smem_batch* b);
+/* Measurement aid: with ACCG_SMEM_COUNT=1 in the environment the batches run a counting build of the same kernels; this returns and
+ * resets {32-byte index sectors fetched, prefix-table entries fetched, bwt_extend calls, 0} (zeros otherwise).  The reference accounts
+ * the blocks it REQUESTS (smem/host/baseline.cpp:28-75); this is what the device fetched. */
+int accg_smem_debug_counts(accg_ctx* ctx, uint64_t out[4]);
 
 /* ---- BWA-MEM seed extension (bwa-sw) ---------------------------------------------------------------------
  * seed_proc + sw_extend of the reference's FPGA kernel (bwa-sw/sdaccel/smithwaterman.cpp:511-672, :75-273): for each seed

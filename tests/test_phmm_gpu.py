@@ -358,3 +358,34 @@ def test_full_size_c3_properties(ctx):
         _, ol10, _ = _oracle_region(reads, haps)
         got = l1[ri * 2048:(ri + 1) * 2048]
         assert np.max(np.abs(got - ol10) / np.abs(ol10)) < REL_TOL
+
+
+def test_ring_equals_one_shot(ctx):
+    """Regions in flight (accg_phmm_ring_*): the same bits as the blocking call, whatever the number of slots; a slot that has not
+    been waited for refuses the next submit."""
+    rng = synth.rng_for(320)
+    regs = [synth.make_region(rng, int(rng.integers(1, 30)), int(rng.integers(1, 9)), (10, 200), (20, 400), n_frac=0.01, unrelated_frac=0.25)
+            for _ in range(13)]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
+    want = [ctx.phmm_region(a, b, n) for a, b, n in ser]
+    for slots in (1, 3, 8):
+        with A.PhmmRing(ctx, slots) as ring:
+            got, tickets = [], []
+            for k, (a, b, n) in enumerate(ser):
+                if len(tickets) == slots:
+                    t, m = tickets.pop(0)
+                    got.append(ring.wait(t, m))
+                tickets.append((ring.submit(a, b), n))
+            while tickets:
+                t, m = tickets.pop(0)
+                got.append(ring.wait(t, m))
+            for (wr, wl, wc), (gr, gl, gc) in zip(want, got):
+                assert wr.tobytes() == gr.tobytes() and wl.tobytes() == gl.tobytes() and wc.rescued == gc.rescued and wc.cells == gc.cells
+            # a full ring refuses a submit, a ticket cannot be waited for twice
+            ts = [ring.submit(ser[0][0], ser[0][1]) for _ in range(slots)]
+            with pytest.raises(A.AccgError):
+                ring.submit(ser[0][0], ser[0][1])
+            for t in ts:
+                ring.wait(t, ser[0][2])
+            with pytest.raises(A.AccgError):
+                ring.wait(ts[0], ser[0][2])
