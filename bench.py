@@ -249,6 +249,26 @@ def bench_sw(ctx, comm, steps, warmup, with_cpu):
     return cells, t1 - t0, extras
 
 
+def random_sectors(sm_tj, algo_lookups_per_read, n_reads, k_ms):
+    """The roof that binds the SMEM kernel: dependent random 32-byte sector reads out of the 64 MB index.  `frac` is priced on the
+    sectors the kernel really fetches (the -DSMEM_COUNT build, tools/smem_counts.py -> profiles/*_smem_counts.json -> traffic.json),
+    which cannot exceed 1; the reference's own count of REQUESTED blocks (smem/host/baseline.cpp:28-75), which the prefix table and the
+    shortened searches partly skip, is given beside it."""
+    perf = (sm_tj or {}).get("performed")
+    out = {"peak": SMEM_SECTOR_PEAK_G, "unit": "G sectors/s",
+           "algorithmic": {"lookups_per_read": algo_lookups_per_read, "rate": algo_lookups_per_read * n_reads / (k_ms * 1e-3) / 1e9,
+                           "note": "block lookups the reference's CPU code requests for these reads (oracle count); not a physical rate"},
+           "note": "peak = dependent pairs of random 32-byte sector reads out of a 64 MB table with all 64 lanes active (tools/ubench_random.hip, "
+                   "profiles/r02_ubench_random.txt)"}
+    if perf:
+        ach = (perf["sectors_per_read"] + perf["table_entries_per_read"]) * n_reads / (k_ms * 1e-3) / 1e9
+        out.update({"achieved": ach, "frac": ach / SMEM_SECTOR_PEAK_G, "performed": perf,
+                    "pmc_source": pmc_source()})
+    else:
+        out.update({"achieved": None, "frac": None})
+    return out
+
+
 def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
     """SMEM leg: configs[4], n_reads x 150 bp (1 % substitutions, both strands) against the 64 MB BWT of a random genome."""
     import acc_genomics_amd as A
@@ -309,12 +329,7 @@ def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
                                "kernel": SMEM_KERNEL_NAME, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
                                "sectors_32B": {"achieved": ach / 2, "frac": ach / 2 / HBM_PEAK_GBS,
                                                "note": "bytes the re-laid-out index really serves: one 32-byte half-block per Occ lookup"},
-                               "random_sectors": {"achieved": lookups_per_read * n_reads / (k_ms * 1e-3) / 1e9, "peak": SMEM_SECTOR_PEAK_G,
-                                                  "unit": "G sectors/s", "frac": lookups_per_read * n_reads / (k_ms * 1e-3) / 1e9 / SMEM_SECTOR_PEAK_G,
-                                                  "note": "the bound that binds: dependent pairs of random 32-byte sector reads out of a 64 MB table, "
-                                                          "all 64 lanes active, measured by tools/ubench_random.hip on MI355X "
-                                                          "(profiles/r02_ubench_random.txt); algorithmic lookups (the reference's count): those that share a sector with their twin, "
-                                                          "are answered by the prefix table or belong to searches the kernel shortens count here too, so frac can exceed 1"},
+                               "random_sectors": random_sectors(sm_tj, lookups_per_read, n_reads, k_ms),
                                "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
                                        "the path is bound by dependent lookups"},
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},

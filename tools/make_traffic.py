@@ -43,6 +43,15 @@ if bw:
     bw["valu_insts_per_pass"] = (bw["valu_insts_per_launch"] or 0) * bw_launches
     out["bwasw"] = bw
 out = {k: v for k, v in out.items() if v}
+# lookups the SMEM kernel really performs on configs[4] (tools/smem_counts.py, the -DSMEM_COUNT build), when measured
+root_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for name in sorted(os.listdir(os.path.join(root_, "profiles")), reverse=True):
+    if name.endswith("_smem_counts.json") and "smem_c4" in out:
+        c = json.load(open(os.path.join(root_, "profiles", name)))
+        out["smem_c4"]["performed"] = {"source": "profiles/" + name, "sectors_per_read": c["sectors_per_read"],
+                                       "table_entries_per_read": c["table_entries_per_read"], "extends_per_read": c["extends_per_read"],
+                                       "reference_block_lookups_per_read": c["reference_block_lookups_per_read"]}
+        break
 out["source"] = os.path.relpath(src, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out["note"] = ("rocprofv3 --pmc, FETCH_SIZE / WRITE_SIZE in separate passes (tools/prof_pmc.sh), mean per dispatch, KiB units; no gfx950 x2 "
                "read correction (no 16 B/lane streaming loads in these kernels: uncalibrated width, treat as a lower bound)")
