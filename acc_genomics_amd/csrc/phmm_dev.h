@@ -186,7 +186,7 @@ constexpr float PHMM_X5_MAX_YY = 0.96875f, PHMM_X5_MIN_MM = 0.0625f;
 // strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in
 // that order of every job that produced a result below PHMM_F64_TINY
 hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s,
-                                  uint32_t grid_cap = PHMM_RESCUE_GRID_DEFAULT);
+                                  uint32_t grid_cap = PHMM_RESCUE_GRID_DEFAULT, bool form5 = false);
 constexpr double PHMM_F64_TINY = 1e-280;      // x 2^1020 scaling included: 28 decades above the smallest normal double
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
 hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);

@@ -262,6 +262,7 @@ struct accg_phmm_batch {
   std::vector<uint8_t> streams;  // the haplotype streams of all runs, laid out for the kernels that copy theirs in (phmm_dev.h: PHMM_STREAM_TAIL)
   std::vector<uint32_t> chunk_stream16, chunk_stream_len;   // per run (index into chunks_dev): offset in 16-byte units / length
   uint64_t n_rows = 0;           // read bases in all = per-row records
+  bool all_form5 = true;         // every read passes the five-operation form's range tests: the fp64 rescue pass may use it too
   bool any_form5 = false;        // some launch runs the five-operation sweep: phmm_prepare_rows runs at the start of a fast pass
   std::vector<uint8_t> rd_form;  // per read: the cheapest form of the fast sweep it passes the range tests of: 5, 6 or 7 (phmm_dev.h)
   std::vector<PhmmWork> work;
@@ -780,7 +781,9 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     a.job_map = nullptr; a.is_redo = 0;
     a.redo_count = strict ? nullptr : b->d_state.p + state_redo(*b) + c;
     a.redo_list = strict ? nullptr : b->d_redo.p + b->rescue_off[c];
-    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, strict, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st));
+    static const bool f5_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_FORM5"); return e && e[0] == '0'; }();   // A/B knob
+    ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, strict, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st, PHMM_RESCUE_GRID_DEFAULT,
+                                    b->all_form5 && !f5_off));
     if (!strict) {        // the jobs that launch listed (results next to the denormal range), in the reference's operation order
       PhmmArgs<double> r = a;
       r.job_count = a.redo_count; r.job_map = a.redo_list; r.redo_count = nullptr; r.redo_list = nullptr; r.is_redo = 1;
@@ -828,6 +831,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
     const int nr = P.nr, nh = P.nh;
     b->rd.insert(b->rd.end(), P.rd.begin(), P.rd.end()); b->rd_form.insert(b->rd_form.end(), P.form.begin(), P.form.end());
+    for (uint8_t f : P.form) b->all_form5 &= f == 5;
     b->hp.insert(b->hp.end(), P.hp.begin(), P.hp.end()); b->hp_ptr.insert(b->hp_ptr.end(), P.hp_ptr.begin(), P.hp_ptr.end());
     b->has_n |= P.has_n;
     r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;

@@ -11,7 +11,10 @@ hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>&
   return launch<double, true, false>(K, lpp, a, wb, n, s, striped);
 }
 hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s,
-                                  uint32_t grid_cap) {
+                                  uint32_t grid_cap, bool form5) {
+  // form5 (fast mode, a batch all of whose reads pass the five-operation form's range tests, classes with the column in assembly):
+  // five fp64 operations per cell instead of seven
+  if (form5 && !strict && !striped && K <= PHMM_ASM_MAX_K_F64) return launch<double, false, true, 5>(K, lpp, a, wb, n, s, striped, grid_cap);
   // strict: the reference's operation order throughout.  Otherwise the 7-op contraction of the fast mode, which is within 1e-8 of
   // it -- except where the fp64 likelihood x 2^1020 comes within ~1e28 of the smallest normal double: there, which values get
   // flushed (x86 FTZ, matched on the device) depends on the last bits of every intermediate, and a contracted result landed

@@ -580,6 +580,54 @@ __device__ __forceinline__ double column_f64_asm(Rows<double, K>& s, DistRegsD<K
   return (LPP == 32 || LPP == 8) ? s.M[K - 1] + s.X[K - 1] : s.x_out;
 }
 
+// ... and the five-operation form in fp64 (the rescue pass of a batch all of whose reads pass the form's range tests): the same
+// arithmetic as column_rows5 in register pairs -- five operations of the half-rate fp64 pipe per cell instead of seven.
+template <int LPP, int K, int Q>
+__device__ __forceinline__ void column_rows5_f64(Rows<double, K>& s, DistRegsD<K>& dq, unsigned addr_next, unsigned tail_adj, double a_in, double x_in,
+                                                 double& tc, double& a_new) {
+  if constexpr (Q < DistRegsD<K>::QT) {
+    lgkm_wait<DistRegsD<K>::QT>();
+#pragma unroll
+    for (int k = 2 * Q; k < 2 * Q + 2 && k < K; k++) {
+      const double dk = dq.get(k);
+      const double gn = (k + 1 < K) ? s.pGM[k + 1] : s.nGM;      // a[k]: what this row's Xs enters the term for the row below with
+      const double mn = (k + 1 < K) ? s.pMM[k + 1] : s.nMM;      // b[k]: ... its Ys
+      double tn;
+      if (k == 0) {
+        asm volatile(
+            "v_fma_f64 %[tn], %[X], %[gn], %[M]\n\t"
+            "v_fma_f64 %[tn], %[Y], %[mn], %[tn]\n\t"
+            "v_fma_f64 %[Y], %[Y], %[xx], %[M]\n\t"
+            "v_mul_f64 %[M], %[d], %[ai]"
+            : [tn] "=&v"(tn), [Y] "+v"(s.Y[0]), [M] "+v"(s.M[0])
+            : [X] "v"(s.X[0]), [gn] "v"(gn), [mn] "v"(mn), [xx] "v"(s.pXX[0]), [d] "v"(dk), [ai] "v"(a_in));
+        s.X[0] = x_in;
+      } else {
+        asm volatile(
+            "v_fma_f64 %[tn], %[X], %[gn], %[M]\n\t"
+            "v_fma_f64 %[X], %[Xp], %[mx], %[Mp]\n\t"
+            "v_fma_f64 %[tn], %[Y], %[mn], %[tn]\n\t"
+            "v_fma_f64 %[Y], %[Y], %[xx], %[M]\n\t"
+            "v_mul_f64 %[M], %[d], %[tc]"
+            : [tn] "=&v"(tn), [X] "+v"(s.X[k]), [Y] "+v"(s.Y[k]), [M] "+v"(s.M[k])
+            : [gn] "v"(gn), [mn] "v"(mn), [xx] "v"(s.pXX[k]), [Xp] "v"(s.X[k - 1]), [Mp] "v"(s.M[k - 1]), [mx] "v"(s.pMX[k]), [d] "v"(dk), [tc] "v"(tc));
+      }
+      if (k + 1 < K) tc = tn; else a_new = tn;
+    }
+    dq.template load<Q>(addr_next, tail_adj);
+    column_rows5_f64<LPP, K, Q + 1>(s, dq, addr_next, tail_adj, a_in, x_in, tc, a_new);
+  }
+}
+template <int LPP, int K>
+__device__ __forceinline__ double column_f64_asm5(Rows<double, K>& s, DistRegsD<K>& dq, unsigned addr_next, unsigned tail_adj) {
+  const double a_in = group_shr1<LPP>(s.a_out), x_in = group_shr1<LPP>(s.x_out);
+  double tc = 0.0, a_new = 0.0;
+  column_rows5_f64<LPP, K, 0>(s, dq, addr_next, tail_adj, a_in, x_in, tc, a_new);
+  s.a_out = a_new;
+  s.x_out = fma_(s.X[K - 1], s.nXX, s.M[K - 1]);           // Xs of row 0 of the lane to the right
+  return fma_(s.X[K - 1], s.xl, s.M[K - 1]);               // M + X of the lane's last row
+}
+
 // what the sweep needs to know about the assembly column of a value type
 template <typename T, int K> struct AsmCol;
 template <int K> struct AsmCol<float, K> {
@@ -588,7 +636,10 @@ template <int K> struct AsmCol<float, K> {
 };
 template <int K> struct AsmCol<double, K> {
   typedef DistRegsD<K> Regs;
-  template <int LPP, int XF> static __device__ __forceinline__ double column(Rows<double, K>& s, Regs& dq, unsigned a, unsigned t) { return column_f64_asm<LPP, K>(s, dq, a, t); }
+  template <int LPP, int XF> static __device__ __forceinline__ double column(Rows<double, K>& s, Regs& dq, unsigned a, unsigned t) {
+    if constexpr (XF == 5) return column_f64_asm5<LPP, K>(s, dq, a, t);
+    else return column_f64_asm<LPP, K>(s, dq, a, t);
+  }
 };
 
 // One wavefront per workgroup (measured: 256-thread workgroups of four independent jobs change nothing and
