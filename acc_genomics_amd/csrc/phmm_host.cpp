@@ -328,17 +328,28 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
   int32_t n; memcpy(&n, p, 4);
   if (n < 0) return ACCG_ERR_BAD_WIRE;
   size_t pos = 4;
-  for (int i = 0; i < n; i++) {
+  const size_t first = refs.size();
+  for (int i = 0; i < n; i++) {                  // the records' lengths, in order (each one's position follows from the ones in front of it)
     if (pos + 4 > bytes) return ACCG_ERR_BAD_WIRE;
     int32_t len; memcpy(&len, p + pos, 4); pos += 4;
     if (len < 0 || pos + 5 * (size_t)len > bytes) return ACCG_ERR_BAD_WIRE;
     if (len == 0) return ACCG_ERR_EMPTY_SEQ;
     if (len > ACCG_PHMM_MAX_READ) return ACCG_ERR_TOO_LONG;
-    for (int k = 0; k < len; k++) if (!valid_base_lut(p[pos + k])) return ACCG_ERR_BAD_BASE;
     refs.push_back({base_off + (uint32_t)pos, (uint32_t)len});
-    form.push_back((uint8_t)phmm_read_form(p + pos, len));
     pos += 5 * (size_t)len;
   }
+  // base validation and the range tests of the sweep's forms, read by read: independent, on the host's threads for a large region
+  // (inside the per-region parallel loop of a multi-region batch this stays serial: no nested teams)
+  form.resize(first + (size_t)n);
+  int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) reduction(| : bad) if (n >= 512)
+  for (int i = 0; i < n; i++) {
+    const SeqRef& r = refs[first + (size_t)i];
+    const uint8_t* q = p + (r.off - base_off);
+    for (uint32_t k = 0; k < r.len; k++) bad |= !valid_base_lut(q[k]);
+    form[first + (size_t)i] = (uint8_t)phmm_read_form(q, (int)r.len);
+  }
+  if (bad) return ACCG_ERR_BAD_BASE;
   return n;
 }
 int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, bool& has_n, std::vector<const uint8_t*>& ptrs) {
