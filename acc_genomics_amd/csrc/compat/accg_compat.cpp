@@ -5,6 +5,7 @@
 #include <string.h>
 #include <fstream>
 #include <sstream>
+#include <chrono>
 #include <stdexcept>
 #include "../../../include/accg.h"
 
@@ -335,10 +336,18 @@ bool FalconSWFPGA_init(char* bitstream) {      // FalconSW_FPGA.cpp:16-27
   return true;
 }
 void FalconSWFPGA_release() { _release_smithWaterman(); }      // FalconSW_FPGA.cpp:92-94
+static FalconSW_cpu_fn g_sw_cpu_fallback = nullptr;
+void FalconSWFPGA_set_cpu_fallback(FalconSW_cpu_fn fn) { g_sw_cpu_fallback = fn; }
 double FalconSWFPGA_run(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int* altLengths, int batchSize, int strategy,
                         int wm, int wx, int wo, int we, struct Cigar* cig, int* offs, bool isFPGA) {
-  if (!isFPGA || batchSize <= 0) return -1;
-  return sw_batch(ref, refLength, &alts[0][0], MAX_SEQ_LENGTH, altLengths, batchSize, strategy, wm, wx, wo, we, cig, offs);
+  if (batchSize <= 0) return -1;
+  double ns = -1;
+  if (isFPGA) ns = sw_batch(ref, refLength, &alts[0][0], MAX_SEQ_LENGTH, altLengths, batchSize, strategy, wm, wx, wo, we, cig, offs);
+  if (ns >= 0 || !g_sw_cpu_fallback) return ns;
+  // FalconSW_FPGA.cpp:43-51: not for the accelerator (or refused by it) -> the caller's CPU code, option 0, timed around the call
+  const auto t0 = std::chrono::steady_clock::now();
+  if (g_sw_cpu_fallback(ref, refLength, alts, batchSize, altLengths, cig, offs, strategy, 0) != 0) return -1;
+  return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
 }
 int SWPairwiseAlignmentMultiBatch(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int batchSize, int* altLengths,
                                   struct Cigar* cig, int* offs, int strategy, int /*option: CPU variant selector*/) {

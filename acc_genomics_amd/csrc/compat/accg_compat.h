@@ -116,8 +116,13 @@ int _init_opencl(const char* bitstream);      // 1: device brought up now; 0: al
 int _init_kernel_buffer();                    // loads the kernels and sizes the context's device / pinned buffers; 0
 int _release_smithWaterman();                 // gives the cached device blocks back; 0
 bool FalconSWFPGA_init(char* bitstream);
-// Returns device time in ns.  Results in place; a batch the device cannot take (length 0 or > 1535)
-// makes it return -1 with nothing written (the reference falls back to its AVX code at this point).
+// Returns device time in ns.  Results in place.  Where the reference computes on the CPU instead (isFPGA false, or a batch its
+// device cannot take: FalconSW_FPGA.cpp:43-51 calls SWPairwiseAlignmentMultiBatch, its AVX code), this library has no CPU path of
+// its own: the caller installs one with FalconSWFPGA_set_cpu_fallback (the reference's own function, which it still links), and
+// FalconSWFPGA_run then calls it and returns its wall time in ns; without one it returns -1 with nothing written.
+typedef int (*FalconSW_cpu_fn)(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int batchSize, int* altLengths, struct Cigar* cigarResults,
+                               int* alignmentOffsets, int overhang_strategy, int option);
+void FalconSWFPGA_set_cpu_fallback(FalconSW_cpu_fn fn);
 double FalconSWFPGA_run(char* ref, int refLength, char alts[][MAX_SEQ_LENGTH], int* altLengths, int batchSize,
                         int overhang_strategy, int w_match, int w_mismatch, int w_open, int w_extend,
                         struct Cigar* cigarResults, int* alignmentOffsets, bool isFPGA);

@@ -152,6 +152,20 @@ static int test_sw() {
     if (FalconSWFPGA_run(ref, rl, alts, altLen, 1, 0, w[0], w[1], w[2], w[3], cig, offs, true) < 0 ||
         cmp_cigar(cig[0], offs[0], ref, rl, alts[0], altLen[0], 0, w)) { printf("sw after release mismatch\n"); bad++; }
   }
+  {   // isFPGA = false: the reference computes on the CPU (FalconSW_FPGA.cpp:43-51).  Without a caller-installed CPU function: -1,
+      // nothing written; with one (here a stand-in that marks its call): it is called and its time returned.
+    char ref[] = "ACGTACGTTAGCAGCATCGATCGACTAGCTAGGATCGATTTAGC";
+    int rl = (int)strlen(ref); altLen[0] = rl; memcpy(alts[0], ref, rl);
+    cig[0].CigarElementNum = -77;
+    if (FalconSWFPGA_run(ref, rl, alts, altLen, 1, 0, w[0], w[1], w[2], w[3], cig, offs, false) != -1 || cig[0].CigarElementNum != -77) { printf("isFPGA=false without a fallback\n"); bad++; }
+    FalconSWFPGA_set_cpu_fallback([](char*, int refLength, char (*)[MAX_SEQ_LENGTH], int B, int*, struct Cigar* c, int* o, int, int option) -> int {
+      for (int k = 0; k < B; k++) { c[k].CigarElementNum = 1; c[k].cigarElements[0].length = refLength; c[k].cigarElements[0].state = STATE_MATCH; o[k] = 40 + option; }
+      return 0;
+    });
+    const double ns = FalconSWFPGA_run(ref, rl, alts, altLen, 1, 0, w[0], w[1], w[2], w[3], cig, offs, false);
+    if (ns < 0 || cig[0].CigarElementNum != 1 || cig[0].cigarElements[0].length != rl || offs[0] != 40) { printf("isFPGA=false with a fallback\n"); bad++; }
+    FalconSWFPGA_set_cpu_fallback(nullptr);
+  }
   printf("htc-sw: %s\n", bad ? "FAILED" : "ok");
   return bad;
 }
