@@ -115,6 +115,7 @@ struct PhmmArgs {
   int lds_min;                // host side only: ask for at least this much dynamic LDS (pins the resident wavefronts per CU)
   uint32_t* zero_words;       // fp32 pass: block 0 of every launch zeroes these n_zero words (rescue job counts, redo counts, the counter of
   int n_zero;                 //   rescued pairs) -- the previous pass is through with them, this pass's planner comes after the sweep (nullable)
+  unsigned long long* clock_out;  // fp32 pass (nullable): the first wavefront of a launch leaves {shader-clock ticks, 100 MHz wall-clock ticks} of its job here
   int fair;                   // assembly sweep: 1 = a wavefront lowers its issue priority as it advances (see phmm_job), 0 = never
   PhmmRowRecs rec;            // five-operation sweep: per-row records (phmm_prepare_rows) ...
   const uint8_t* streams;     // ... and the streams laid out at batch creation

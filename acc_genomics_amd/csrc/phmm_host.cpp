@@ -278,6 +278,7 @@ struct accg_phmm_batch {
   DevBuf<PhmmHapDesc> d_hap_desc;   // hap_ids with the haplotype's descriptor next to each id
   DevBuf<PhmmWork> d_work;
   DevBuf<uint32_t> d_rd_row0, d_rd_shape;
+  DevBuf<uint64_t> d_clock;      // {shader-clock ticks, wall-clock ticks} of the first wavefront of the last sweep launch
   DevBuf<uint8_t> d_streams;
   DevBuf<float4> d_rec_coef, d_rec_dist, d_rec_misc;
   DevBuf<float> d_out;
@@ -719,7 +720,7 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   a.job_map = nullptr; a.redo_count = nullptr; a.redo_list = nullptr; a.is_redo = 0;
   a.rec = PhmmRowRecs{b.d_rec_coef.p, b.d_rec_dist.p, b.d_rec_misc.p, b.d_rd_row0.p, b.d_rd_shape.p};
   a.streams = b.d_streams.p;
-  a.fair = 0; a.zero_words = nullptr; a.n_zero = 0;
+  a.fair = 0; a.zero_words = nullptr; a.n_zero = 0; a.clock_out = nullptr;
   return a;
 }
 
@@ -734,6 +735,7 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
     ACCG_HIP(phmm_prepare_rows_launch(a, (uint32_t)b->rd.size(), nullptr, 0, b->ctx->stream));
   a.zero_words = b->d_state.p + state_counts(*b);
   a.n_zero = (int)(state_words(*b) - state_counts(*b));
+  a.clock_out = reinterpret_cast<unsigned long long*>(b->d_clock.p);
   if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
   const bool fork = b->launches.size() > 1;          // several rows-per-lane classes: run them side by side
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
@@ -887,6 +889,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   if (b->n_rows >= (1ull << 32)) return ACCG_ERR_TOO_LONG;
   const size_t n_rec = (size_t)b->n_rows + 1;
   const size_t o_rec_coef = take(n_rec * sizeof(float4)), o_rec_dist = take(n_rec * sizeof(float4)), o_rec_misc = take(n_rec * sizeof(float4));
+  const size_t o_clock = take(4 * sizeof(uint64_t));
   const size_t o_flagged = take((b->rd.size() + 1) * sizeof(uint32_t));
   const size_t o_jobs = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(PhmmWork));
   const size_t o_redo = take(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(uint32_t));
@@ -904,6 +907,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
   b->d_rd_row0.place(base, o_row0, b->rd_row0.size()); b->d_rd_shape.place(base, o_shape, b->rd_shape.size()); b->d_streams.place(base, o_streams, b->streams.size() + 16);
   b->d_rec_coef.place(base, o_rec_coef, n_rec); b->d_rec_dist.place(base, o_rec_dist, n_rec); b->d_rec_misc.place(base, o_rec_misc, n_rec);
+  b->d_clock.place(base, o_clock, 4);
   b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
   b->d_rescue_jobs.place(base, o_jobs, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
   b->d_redo.place(base, o_redo, (size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1);
@@ -1063,6 +1067,20 @@ extern "C" int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int it
   for (int i = 0; i < iters; i++) { float k = 0; ACCG_HIP(hipEventElapsedTime(&k, ev[2 * i], ev[2 * i + 1])); sum += k; }
   *kernel_ms = (float)(sum / iters);
   b->last_kernel_ns = (uint64_t)((double)ms / iters * 1e6);
+  return ACCG_OK;
+}
+// The shader clock the device held while the first wavefront of the last sweep launch ran its job (s_memtime ticks over 100 MHz
+// wall-clock ticks, both taken by that wavefront): the clock UNDER the kernel, not that of an idle or lightly loaded card.
+extern "C" int accg_phmm_batch_clock_ghz(accg_phmm_batch* b, float* ghz) {
+  if (!b || !ghz) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  uint64_t h[2] = {0, 0};
+  ACCG_HIP(hipMemcpy(h, b->d_clock.p, sizeof h, hipMemcpyDeviceToHost));
+  int wall_khz = 0;
+  ACCG_HIP(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, b->ctx->device));
+  if (wall_khz <= 0) wall_khz = 100000;
+  *ghz = h[1] ? (float)((double)h[0] / (double)h[1] * (double)wall_khz * 1e-6) : 0.f;
   return ACCG_OK;
 }
 extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, float* ms_per_run) {

@@ -1228,7 +1228,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(phmm_min
   if (!RESCUE && a.zero_words && blockIdx.x == 0)          // see PhmmArgs::zero_words
     for (int i = threadIdx.x; i < a.n_zero; i += 64 * W) a.zero_words[i] = 0u;
   if constexpr (W > 1) {
+    // (the launch's first wavefront times its own job on the shader clock and on the constant-rate wall clock: the clock the
+    // card holds UNDER THIS KERNEL, which a bench line quotes next to the fraction of the issue roof)
+    const bool probe = !RESCUE && a.clock_out && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;   // (uniform: the ticks stay scalar)
+    unsigned c0 = 0, w0 = 0;                   // (low words: a job lasts well under the two seconds they wrap in)
+    if (probe) { c0 = (unsigned)__builtin_amdgcn_s_memtime(); w0 = (unsigned)wall_clock64(); }
     phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED, W>(a, work_base, blockIdx.x * W + (threadIdx.x >> 6));
+    if (probe && threadIdx.x == 0) { a.clock_out[0] = (unsigned)__builtin_amdgcn_s_memtime() - c0; a.clock_out[1] = (unsigned)wall_clock64() - w0; }
     return;
   }
   if (RESCUE && a.job_count) {
@@ -1250,7 +1256,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(phmm_min
       if (!STRICT && tiny && a.redo_count && threadIdx.x == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = job;
     }
   } else {
+    const bool probe = !RESCUE && a.clock_out && blockIdx.x == 0;
+    unsigned c0 = 0, w0 = 0;
+    if (probe) { c0 = (unsigned)__builtin_amdgcn_s_memtime(); w0 = (unsigned)wall_clock64(); }
     phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED>(a, work_base, blockIdx.x);
+    if (probe && threadIdx.x == 0) { a.clock_out[0] = (unsigned)__builtin_amdgcn_s_memtime() - c0; a.clock_out[1] = (unsigned)wall_clock64() - w0; }
   }
 }
 

@@ -62,6 +62,7 @@ def load():
     L.accg_phmm_batch_time2.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_phmm_batch_time_in_step.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.accg_ctx_clock_ghz.argtypes = [vp, C.POINTER(C.c_float)]
+    L.accg_phmm_batch_clock_ghz.argtypes = [vp, C.POINTER(C.c_float)]
     L.accg_phmm_batch_results.argtypes = [vp, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_batch_destroy.argtypes = [vp]
     L.accg_counters_pack.argtypes = [C.POINTER(Counters), C.POINTER(C.c_uint64)]
@@ -241,6 +242,12 @@ class PhmmBatch:
         k, s = C.c_float(), C.c_float()
         _check(self.L.accg_phmm_batch_time_in_step(self.h, mode, iters, C.byref(k), C.byref(s)))
         return k.value, s.value
+
+    def clock_ghz(self):
+        """accg_phmm_batch_clock_ghz: the shader clock held under the last sweep launch (its first wavefront's own measurement)."""
+        g = C.c_float()
+        _check(self.L.accg_phmm_batch_clock_ghz(self.h, C.byref(g)))
+        return g.value
 
     def results(self, want_log10=True):
         raw = np.zeros(self.pairs, np.float32)

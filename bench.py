@@ -670,7 +670,8 @@ def main():
     # as many whole passes again (plain stream launches of the same kernels), each with HIP events around its fp32 sweep launch on
     # the stream it is launched on (accg_phmm_batch_time_in_step); then the shader clock the card holds under load.
     k_ms, step_ev_ms = batch.time_in_step(mode, iters=min(max(args.steps, 5), 1000))
-    clock_ghz = ctx.clock_ghz()
+    clock_ghz = batch.clock_ghz()        # measured by the sweep kernel itself (its first wavefront: shader-clock over wall-clock ticks)
+    clock_probe_ghz = ctx.clock_ghz()    # ... and what a light 0.3 ms fp32 kernel holds right behind it
     raw, _, cnt = batch.results(want_log10=False)
 
     # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks -- all four as totals over the timed steps -- and the
@@ -738,6 +739,8 @@ def main():
                 "valu_frac": flops / 157.3e12,
                 "issue_frac": issue["frac"] if issue else None,
                 "clock_ghz_held": clock_ghz,
+                "clock_ghz_how": "shader-clock ticks over 100 MHz wall-clock ticks of the first wavefront of the last timed sweep launch, taken by "
+                                 "that wavefront (accg_phmm_batch_clock_ghz); a light fp32 probe kernel right behind held %.3f GHz" % clock_probe_ghz,
                 "issue_frac_at_clock_held": (issue["ideal_ms"] * (CLOCK_HZ / 1e9) / clock_ghz / k_ms) if issue and clock_ghz > 0 else None,
                 "pmc_source": pmc_source(),
                 "valu": {"achieved_tflops": flops / 1e12, "peak_tflops": 157.3, "frac": flops / 157.3e12, "issue": issue,

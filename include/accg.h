@@ -110,6 +110,9 @@ int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float*
 /* the shader clock the device holds under load right now, in GHz: a ~0.3 ms full-chip fp32 kernel whose first wavefront reads the
  * shader-clock counter and the constant-rate wall clock at both ends */
 int accg_ctx_clock_ghz(accg_ctx* ctx, float* ghz);
+/* ... and the shader clock held while the first wavefront of the batch's last sweep launch ran (its own shader-clock ticks over its
+ * own 100 MHz wall-clock ticks): the clock under the PairHMM kernel itself */
+int accg_phmm_batch_clock_ghz(accg_phmm_batch* b, float* ghz);
 uint64_t accg_phmm_batch_jobs(const accg_phmm_batch* b);
 /* Context<float>/<double> tables as uploaded (ph2pr[128], matchToMatchProb[8256], INITIAL_CONSTANT, its log10) */
 void accg_phmm_tables_f32(float* ph2pr, float* m2m, float* init, float* log10_init);
