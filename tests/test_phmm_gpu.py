@@ -389,3 +389,15 @@ def test_ring_equals_one_shot(ctx):
                 ring.wait(t, ser[0][2])
             with pytest.raises(A.AccgError):
                 ring.wait(ts[0], ser[0][2])
+
+
+def test_time_in_step_and_clock(ctx):
+    """The bench's instruments: the sweep timed inside whole passes (events on its launch stream) is shorter than the pass, and the
+    clock the sweep kernel measures on itself is a plausible shader clock."""
+    rng = synth.rng_for(330)
+    reads, haps = synth.make_region(rng, 256, 8, 101, 300)
+    with A.PhmmBatch(ctx, [(synth.serialize_reads(reads), synth.serialize_haps(haps))]) as b:
+        k_ms, step_ms = b.time_in_step(A.ACCG_PHMM_FAST, iters=5)
+        assert 0 < k_ms <= step_ms < 50
+        assert 0.5 < b.clock_ghz() < 3.0
+        assert 0.5 < ctx.clock_ghz() < 3.0

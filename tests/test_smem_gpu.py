@@ -172,3 +172,39 @@ def test_full_size_c4_properties(ctx):
     orc.oracle().orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, S, 64, want.ctypes.data, wnum.ctypes.data, 16)
     assert np.array_equal(num[:S], wnum)
     assert all(np.array_equal(got[k, :wnum[k]], want[k, :wnum[k]]) for k in range(S))
+
+
+def test_counting_build_counts_performed_lookups(tmp_path):
+    """ACCG_SMEM_COUNT=1 selects the counting build of the same kernels (own process: the switch is read once): same intervals, and
+    counters that say what the device fetched -- at least one index sector per bwt_extend, at most two."""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, json, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import acc_genomics_amd as A
+from acc_genomics_amd import fmindex, synth
+import orc
+rng = synth.rng_for(77)
+g = rng.integers(0, 4, size=20000).astype(np.uint8)
+bwt, para, _ = fmindex.build(g)
+reads = [g[o:o + 120].copy() for o in rng.integers(0, 19800, size=256)]
+seq, ln = fmindex.encode_reads(reads)
+O = orc.oracle()
+want = np.zeros((256, 64, 4), np.uint64); wnum = np.zeros(256, np.int32)
+O.orc_smem_batch(bwt.ctypes.data, para.ctypes.data, seq.ctypes.data, 256, ln.ctypes.data, 256, 64, want.ctypes.data, wnum.ctypes.data, 2)
+with A.Context(0) as ctx, A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, 64) as sb:
+    cnt = (C.c_uint64 * 4)()
+    ctx.L.accg_smem_debug_counts(ctx.h, cnt)
+    sb.run()
+    got, gnum = sb.results()
+    ctx.L.accg_smem_debug_counts(ctx.h, cnt)
+ok = bool(np.array_equal(gnum, wnum) and all(np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]) for k in range(256)))
+print(json.dumps({"ok": ok, "cnt": [int(x) for x in cnt]}))
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, ACCG_SMEM_COUNT="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    sectors, table, extends, _ = out["cnt"]
+    assert out["ok"] and extends > 0 and extends <= sectors <= 2 * extends and table >= 0
