@@ -606,63 +606,96 @@ void partition(accg_phmm_batch& b) {
   struct Job { PhmmWork w, w2; int K, lpp, form; bool striped; int wg; uint64_t cost; uint32_t stream_len; };
   std::vector<Job> jobs;
   uint32_t cap_all = 0, hmax_all = 1;
+  // Two passes over the regions.  The first, serial and cheap, cuts each region's haplotypes into runs and hands out the places of
+  // what the second one writes (run table, haplotype lists, streams, jobs); the second fills them region by region, independently,
+  // on the host's threads.
+  struct RegPlan { std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens; uint32_t chunk0 = 0, ids0 = 0, job0 = 0, n_jobs = 0; size_t stream0 = 0; };
+  std::vector<RegPlan> plan(b.regions.size());
+  {
+    uint32_t chunk0 = 0, ids0 = 0; size_t stream0 = 0;
+    for (size_t ri = 0; ri < b.regions.size(); ri++) {
+      if (groups[ri].empty()) continue;
+      const Region& r = b.regions[ri];
+      RegPlan& P = plan[ri];
+      chunk_region(b, r, best_budget, P.runs, P.lens);
+      P.chunk0 = chunk0; P.ids0 = ids0; P.stream0 = stream0;
+      for (size_t c = 0; c < P.runs.size(); c++) {
+        cap_all = std::max(cap_all, (P.lens[c] + 63) / 64 * 64); hmax_all = std::max(hmax_all, P.runs[c].second);
+        ids0 += P.runs[c].second;
+        stream0 += (P.lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16;
+        b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((P.lens[c] + 63) / 64 * 64));
+        b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)P.runs[c].second);
+      }
+      chunk0 += (uint32_t)P.runs.size();
+      b.regions_dev[ri] = {r.read0, r.n_reads, P.chunk0, (uint32_t)P.runs.size(), r.n_haps, 0};
+      {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
+        uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
+        for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
+        for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)P.runs.size();
+      }
+    }
+    b.chunks_dev.resize(chunk0); b.chunk_stream16.resize(chunk0); b.chunk_stream_len.resize(chunk0);
+    b.hap_ids.resize(ids0);
+    b.streams.assign(stream0, 0);
+  }
+  // pairs of runs for one workgroup of two wavefronts (same reads, one dist table): five-operation form only, not the short reads
+  // that run in the reference's operation order, and only where it buys occupancy at the batch's LDS caps
+  auto paired = [&](const Group& Q) { return best_pairs && Q.form == 5 && !Q.striped && Q.lpp * Q.K > 16 && pairs_pay(Q.K, nchar, (int)cap_all, (int)hmax_all, Q.lpp); };
+  {
+    uint32_t job0 = 0;
+    for (size_t ri = 0; ri < b.regions.size(); ri++) {
+      RegPlan& P = plan[ri];
+      P.job0 = job0;
+      for (const Group& Q : groups[ri]) P.n_jobs += (uint32_t)(paired(Q) ? (P.runs.size() + 1) / 2 : P.runs.size());
+      job0 += P.n_jobs;
+    }
+    jobs.resize(job0);
+  }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (b.regions.size() >= 8)
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (groups[ri].empty()) continue;
     const Region& r = b.regions[ri];
-    std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
-    chunk_region(b, r, best_budget, runs, lens);
-    std::vector<uint32_t> ids0;
-    for (size_t c = 0; c < runs.size(); c++) { cap_all = std::max(cap_all, (lens[c] + 63) / 64 * 64); hmax_all = std::max(hmax_all, runs[c].second); }
-    b.regions_dev[ri] = {r.read0, r.n_reads, (uint32_t)b.chunks_dev.size(), (uint32_t)runs.size(), r.n_haps, 0};
+    const RegPlan& P = plan[ri];
+    const auto& runs = P.runs; const auto& lens = P.lens;
+    std::vector<uint32_t> ids0(runs.size());
+    uint32_t idp = P.ids0; size_t sp = P.stream0;
     for (size_t c = 0; c < runs.size(); c++) {
-      auto& run = runs[c];
-      ids0.push_back((uint32_t)b.hap_ids.size());
-      b.chunks_dev.push_back({(uint32_t)b.hap_ids.size(), run.second});
-      for (uint32_t k = 0; k < run.second; k++) b.hap_ids.push_back(r.hap0 + run.first + k);
-      {   // the run's stream: [marker][codes] per haplotype, a last marker, zeros (phmm_dev.h)
-        b.chunk_stream16.push_back((uint32_t)(b.streams.size() / 16));
-        b.chunk_stream_len.push_back(lens[c]);
-        const size_t at = b.streams.size();
-        b.streams.resize(at + (lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16, 0);
-        size_t w_ = at;
-        for (uint32_t k = 0; k < run.second; k++) {
-          const SeqRef& h = b.hp[r.hap0 + run.first + k];
-          b.streams[w_++] = (uint8_t)nchar;
-          const uint8_t* src = b.hp_ptr[r.hap0 + run.first + k];
-          for (uint32_t x = 0; x < h.len; x++) { const uint8_t ch = src[x]; b.streams[w_++] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
-        }
+      const auto& run = runs[c];
+      ids0[c] = idp;
+      b.chunks_dev[P.chunk0 + c] = {idp, run.second};
+      for (uint32_t k = 0; k < run.second; k++) b.hap_ids[idp++] = r.hap0 + run.first + k;
+      // the run's stream: [marker][codes] per haplotype, a last marker, zeros (phmm_dev.h)
+      b.chunk_stream16[P.chunk0 + c] = (uint32_t)(sp / 16);
+      b.chunk_stream_len[P.chunk0 + c] = lens[c];
+      size_t w_ = sp;
+      for (uint32_t k = 0; k < run.second; k++) {
+        const SeqRef& h = b.hp[r.hap0 + run.first + k];
         b.streams[w_++] = (uint8_t)nchar;
+        const uint8_t* src = b.hp_ptr[r.hap0 + run.first + k];
+        for (uint32_t x = 0; x < h.len; x++) { const uint8_t ch = src[x]; b.streams[w_++] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
       }
-      b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((lens[c] + 63) / 64 * 64));
-      b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)run.second);
+      b.streams[w_++] = (uint8_t)nchar;
+      sp += (lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16;
     }
-    {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
-      uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
-      for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
-      for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)runs.size();
-    }
+    uint32_t jp = P.job0;
     for (const Group& Q : groups[ri]) {
       PhmmWork w;
       for (int g = 0; g < PHMM_GROUPS; g++) w.read[g] = Q.read[g];
       w.pad_[0] = w.pad_[1] = 0;
-      // pairs of runs for one workgroup of two wavefronts (same reads, one dist table): five-operation form only, not the short
-      // reads that run in the reference's operation order, and only where it buys occupancy.  (cap_all / hmax_all: the LDS caps so far
-      // -- a launch's own caps are only known at the end; this one decision may come out differently for the first regions of a batch.)
-      const bool pair = best_pairs && Q.form == 5 && !Q.striped && Q.lpp * Q.K > 16 && pairs_pay(Q.K, nchar, (int)cap_all, (int)hmax_all, Q.lpp);
-      const uint32_t chunk0 = b.regions_dev[ri].chunk0;
+      const bool pair = paired(Q);
       for (size_t c = 0; c < runs.size(); c += pair ? 2 : 1) {
         w.hap_off = ids0[c]; w.n_haps = runs[c].second;
-        w.pad_[0] = b.chunk_stream16[chunk0 + c]; w.pad_[1] = b.chunk_stream_len[chunk0 + c];
+        w.pad_[0] = b.chunk_stream16[P.chunk0 + c]; w.pad_[1] = b.chunk_stream_len[P.chunk0 + c];
         PhmmWork w2 = w;
         uint32_t len = lens[c];
         if (pair) {
           if (c + 1 < runs.size()) {
             w2.hap_off = ids0[c + 1]; w2.n_haps = runs[c + 1].second; len = std::max(len, lens[c + 1]);
-            w2.pad_[0] = b.chunk_stream16[chunk0 + c + 1]; w2.pad_[1] = b.chunk_stream_len[chunk0 + c + 1];
+            w2.pad_[0] = b.chunk_stream16[P.chunk0 + c + 1]; w2.pad_[1] = b.chunk_stream_len[P.chunk0 + c + 1];
           } else { w2.hap_off = 0; w2.n_haps = 0; w2.pad_[0] = w2.pad_[1] = 0; }
         }
         const uint64_t stripes = Q.striped ? (b.rd[Q.read[0]].len + 1024) / 1024 : 1;
-        jobs.push_back({w, w2, Q.K, Q.lpp, Q.form, Q.striped, pair ? 2 : 1, stripes * (uint64_t)(len + 45) * (uint64_t)(8 * Q.K + 10), len});
+        jobs[jp++] = {w, w2, Q.K, Q.lpp, Q.form, Q.striped, pair ? 2 : 1, stripes * (uint64_t)(len + 45) * (uint64_t)(8 * Q.K + 10), len};
       }
     }
   }
