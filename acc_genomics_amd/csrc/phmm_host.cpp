@@ -214,7 +214,7 @@ namespace {
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
 // form: 7, 6 or 5 operations per cell; wg = 2: the work items come in pairs (same reads, two runs of haplotypes; the second may be
 // empty) that the fast kernel runs as one workgroup of two wavefronts sharing the dist table
-struct KLaunch { int K, lpp, form; bool striped; int wg; uint32_t work0, n_work; int stream_cap, haps_cap; };
+struct KLaunch { int K, lpp, form; bool striped; int wg; uint32_t work0, n_work; int stream_cap, haps_cap; uint64_t cost = 0; int aux = 0; };
 
 thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
 struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
@@ -720,14 +720,32 @@ void partition(accg_phmm_batch& b) {
   for (size_t i = 0; i < jobs.size(); i++) {
     if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().form != jobs[i].form ||
         b.launches.back().striped != jobs[i].striped || b.launches.back().wg != jobs[i].wg)
-      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].form, jobs[i].striped, jobs[i].wg, (uint32_t)b.work.size(), 0, 0, 0});
+      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].form, jobs[i].striped, jobs[i].wg, (uint32_t)b.work.size(), 0, 0, 0, 0, 0});
     KLaunch& L = b.launches.back();
     b.work.push_back(jobs[i].w);
     if (jobs[i].wg == 2) b.work.push_back(jobs[i].w2);
     L.n_work += (uint32_t)jobs[i].wg;
+    L.cost += jobs[i].cost * (uint64_t)jobs[i].wg;
     b.any_form5 |= jobs[i].form == 5 && !jobs[i].striped && jobs[i].lpp * jobs[i].K > 16;
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
     L.haps_cap = std::max(L.haps_cap, (int)std::max(jobs[i].w.n_haps, jobs[i].wg == 2 ? jobs[i].w2.n_haps : 0u));
+  }
+  {   // which forked stream takes which launch: ACCG_PHMM_AUX = streams used (default all), ACCG_PHMM_LPT=1: longest first onto the
+      // least loaded stream instead of round robin in class order
+    const char* ea = getenv("ACCG_PHMM_AUX"); const char* el = getenv("ACCG_PHMM_LPT");
+    const int n_aux = std::max(1, std::min((int)accg_ctx::N_AUX, ea ? atoi(ea) : (int)accg_ctx::N_AUX));
+    if (el && el[0] == '1') {
+      std::vector<size_t> idx(b.launches.size());
+      std::iota(idx.begin(), idx.end(), (size_t)0);
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return b.launches[x].cost > b.launches[y].cost; });
+      std::vector<uint64_t> load((size_t)n_aux, 0);
+      for (size_t i : idx) {
+        const int q = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        b.launches[i].aux = q; load[(size_t)q] += b.launches[i].cost;
+      }
+    } else {
+      for (size_t i = 0; i < b.launches.size(); i++) b.launches[i].aux = (int)(i % (size_t)n_aux);
+    }
   }
   if (trace_p) {
     auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
@@ -772,10 +790,9 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
   if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
   const bool fork = b->launches.size() > 1;          // several rows-per-lane classes: run them side by side
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
-  int rr = 0;
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
-    hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : b->ctx->stream;
+    hipStream_t st = fork ? b->ctx->aux[l.aux] : b->ctx->stream;
     const bool strict_l = mode == ACCG_PHMM_STRICT || l.lpp * l.K <= 16;
     // pinned occupancy: the launch asks for as much LDS as leaves exactly 8, 16 or 32 of its wavefronts on a CU
     const int wg = strict_l ? 1 : l.wg;         // a strict launch runs the items of a pair as two wavefronts of their own
