@@ -1292,24 +1292,26 @@ extern "C" int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** 
   return ACCG_OK;
 }
 
-extern "C" int accg_phmm_ring_submit(accg_phmm_ring* r, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
-                                     int mode, uint64_t* ticket) {
-  if (!r || !ticket) return ACCG_ERR_BAD_ARG;
+extern "C" int accg_phmm_ring_submit_many(accg_phmm_ring* r, int n_regions, const void* const* reads_ser, const size_t* reads_bytes,
+                                          const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t* ticket) {
+  if (!r || !ticket || n_regions < 1 || !reads_ser || !reads_bytes || !haps_ser || !haps_bytes) return ACCG_ERR_BAD_ARG;
   const size_t slot = (size_t)(r->next_ticket % r->ctx.size());
-  if (r->batch[slot]) return ACCG_ERR_BAD_ARG;                 // the slot's previous region has not been waited for
+  if (r->batch[slot]) return ACCG_ERR_BAD_ARG;                 // the slot's previous ticket has not been waited for
   accg_ctx* c = r->ctx[slot];
   ACCG_HIP(hipSetDevice(c->device));
   // pinned staging large enough for the upload AND the downloads, before anything is queued (it must not move in between)
-  if (reads_bytes < 4 || haps_bytes < 4) return ACCG_ERR_BAD_WIRE;
-  int32_t nr = 0, nh = 0;
-  memcpy(&nr, reads_ser, 4); memcpy(&nh, haps_ser, 4);
-  if (nr < 0 || nh < 0) return ACCG_ERR_BAD_WIRE;
+  uint64_t pairs = 0; size_t blob = 0;
+  for (int i = 0; i < n_regions; i++) {
+    if (reads_bytes[i] < 4 || haps_bytes[i] < 4 || !reads_ser[i] || !haps_ser[i]) return ACCG_ERR_BAD_WIRE;
+    int32_t nr = 0, nh = 0;
+    memcpy(&nr, reads_ser[i], 4); memcpy(&nh, haps_ser[i], 4);
+    if (nr < 0 || nh < 0) return ACCG_ERR_BAD_WIRE;
+    pairs += (uint64_t)nr * (uint64_t)nh; blob += reads_bytes[i] + haps_bytes[i];
+  }
   void* stage = nullptr;
-  ACCG_HIP(ctx_stage(c, std::max(results_stage_bytes((uint64_t)nr * (uint64_t)nh), 2 * (reads_bytes + haps_bytes) + ((size_t)1 << 20)), &stage));
+  ACCG_HIP(ctx_stage(c, std::max(results_stage_bytes(pairs), 3 * blob + ((size_t)1 << 20)), &stage));
   accg_phmm_batch* b = nullptr;
-  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
-  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
-  int st = accg_phmm_batch_create(c, 1, rs, rb, hs, hb, &b);
+  int st = accg_phmm_batch_create(c, n_regions, reads_ser, reads_bytes, haps_ser, haps_bytes, &b);
   if (st != ACCG_OK) return st;
   b->graph_off = true;
   st = accg_phmm_batch_run(b, mode);
@@ -1318,6 +1320,12 @@ extern "C" int accg_phmm_ring_submit(accg_phmm_ring* r, const void* reads_ser, s
   r->batch[slot] = b;
   *ticket = r->next_ticket++;
   return ACCG_OK;
+}
+extern "C" int accg_phmm_ring_submit(accg_phmm_ring* r, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
+                                     int mode, uint64_t* ticket) {
+  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
+  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
+  return accg_phmm_ring_submit_many(r, 1, rs, rb, hs, hb, mode, ticket);
 }
 
 extern "C" int accg_phmm_ring_wait(accg_phmm_ring* r, uint64_t ticket, float* out_raw, double* out_log10, accg_counters* cnt) {

@@ -49,6 +49,7 @@ def load():
     L.accg_phmm_region_f64.argtypes = [vp, vp, sz, vp, sz, vp]
     L.accg_phmm_ring_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.accg_phmm_ring_submit.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.POINTER(C.c_uint64)]
+    L.accg_phmm_ring_submit_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.c_int, C.POINTER(C.c_uint64)]
     L.accg_phmm_ring_wait.argtypes = [vp, C.c_uint64, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_ring_destroy.argtypes = [vp]
     L.accg_phmm_batch_create.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
@@ -189,6 +190,18 @@ class PhmmRing:
     def submit(self, reads_ser, haps_ser, mode=ACCG_PHMM_FAST):
         t = C.c_uint64()
         _check(self.L.accg_phmm_ring_submit(self.h, reads_ser, len(reads_ser), haps_ser, len(haps_ser), mode, C.byref(t)))
+        return t.value
+
+    def submit_many(self, regions, mode=ACCG_PHMM_FAST):
+        """regions: list of (reads_ser, haps_ser); one ticket, results concatenated in region order."""
+        n = len(regions)
+        keep = [(bytes(r), bytes(h)) for r, h in regions]
+        rs = (C.c_void_p * n)(*[C.cast(C.c_char_p(r), C.c_void_p) for r, _ in keep])
+        hs = (C.c_void_p * n)(*[C.cast(C.c_char_p(h), C.c_void_p) for _, h in keep])
+        rb = (C.c_size_t * n)(*[len(r) for r, _ in keep])
+        hb = (C.c_size_t * n)(*[len(h) for _, h in keep])
+        t = C.c_uint64()
+        _check(self.L.accg_phmm_ring_submit_many(self.h, n, rs, rb, hs, hb, mode, C.byref(t)))
         return t.value
 
     def wait(self, ticket, n_pairs, want_log10=True):

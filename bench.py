@@ -559,6 +559,26 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
                                 "what": "accg_phmm_ring_submit / _wait, four regions in flight, one caller thread; " + what}
         out["c3_slice_one_batch"] = {"regions": n_c3, "ms_total": t_batch * 1e3, "value": c3_cells / t_batch / 1e9, "unit": "GCUPS",
                                      "what": "all regions handed over at once: accg_phmm_batch_create + _run + _results; " + what}
+        # a longer stream in tickets of 32 regions, three tickets in flight: the host half of ticket i + 1 behind the device half of ticket i
+        n_st, G = 4 * n_c3, 32
+        regs2 = regs + [c3_region(k) for k in range(n_c3, n_st)]
+        ser2 = ser + [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs2[n_c3:]]
+        st_cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs2)
+
+        def stream():
+            pend = []
+            for g0 in range(0, n_st, G):
+                if len(pend) == 3:
+                    t, mm = pend.pop(0)
+                    rg3.wait(t, mm)
+                pend.append((rg3.submit_many([(a, b) for a, b, _ in ser2[g0:g0 + G]], mode), sum(m for _, _, m in ser2[g0:g0 + G])))
+            for t, mm in pend:
+                rg3.wait(t, mm)
+
+        with A.PhmmRing(ctx, 3) as rg3:
+            t_stream = med(stream)
+        out["c3_stream"] = {"regions": n_st, "regions_per_ticket": G, "tickets_in_flight": 3, "ms_total": t_stream * 1e3, "value": st_cells / t_stream / 1e9,
+                            "unit": "GCUPS", "what": "accg_phmm_ring_submit_many / _wait over the first %d configs[3] regions, one caller thread, median of 3 passes" % n_st}
     out["note"] = "host memory to host memory, parse + job sizing + upload + kernels + download + log10 all inside; not the headline value"
     return out
 

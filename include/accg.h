@@ -94,6 +94,9 @@ typedef struct accg_phmm_ring accg_phmm_ring;
 int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out);
 int accg_phmm_ring_submit(accg_phmm_ring* ring, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
                           int mode, uint64_t* ticket);
+/* several regions under one ticket (one device batch: its results come back concatenated in region order, like accg_phmm_batch_results) */
+int accg_phmm_ring_submit_many(accg_phmm_ring* ring, int n_regions, const void* const* reads_ser, const size_t* reads_bytes,
+                               const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t* ticket);
 int accg_phmm_ring_wait(accg_phmm_ring* ring, uint64_t ticket, float* out_raw, double* out_log10, accg_counters* counters);
 void accg_phmm_ring_destroy(accg_phmm_ring* ring);
 

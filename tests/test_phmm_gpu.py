@@ -381,6 +381,11 @@ def test_ring_equals_one_shot(ctx):
                 got.append(ring.wait(t, m))
             for (wr, wl, wc), (gr, gl, gc) in zip(want, got):
                 assert wr.tobytes() == gr.tobytes() and wl.tobytes() == gl.tobytes() and wc.rescued == gc.rescued and wc.cells == gc.cells
+            # several regions under one ticket: the concatenation of their results
+            t = ring.submit_many([(a, b) for a, b, _ in ser[:5]])
+            gr, gl, gc = ring.wait(t, sum(n for _, _, n in ser[:5]))
+            assert gr.tobytes() == b"".join(w[0].tobytes() for w in want[:5]) and gl.tobytes() == b"".join(w[1].tobytes() for w in want[:5])
+            assert gc.rescued == sum(w[2].rescued for w in want[:5])
             # a full ring refuses a submit, a ticket cannot be waited for twice
             ts = [ring.submit(ser[0][0], ser[0][1]) for _ in range(slots)]
             with pytest.raises(A.AccgError):

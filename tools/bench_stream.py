@@ -48,6 +48,20 @@ with A.Context(0) as ctx:
                     ring.wait(t, m)
                 t1 = time.perf_counter() - t0
         print("ring of %d slots, one thread: %.3f ms (%.1f us per region), %.0f GCUPS" % (slots, t1 * 1e3, t1 / N * 1e6, cells / t1 / 1e9))
+    for G in (8, 16, 32):
+        with A.PhmmRing(ctx, 3) as ring:
+            for rep in range(3):
+                t0 = time.perf_counter()
+                pend = []
+                for g0 in range(0, N, G):
+                    grp = ser[g0:g0 + G]
+                    if len(pend) == 3:
+                        t, m = pend.pop(0); ring.wait(t, m)
+                    pend.append((ring.submit_many(grp), sum(len(r) * len(h) for r, h in regs[g0:g0 + G])))
+                for t, m in pend:
+                    ring.wait(t, m)
+                t1 = time.perf_counter() - t0
+        print("ring, tickets of %d regions, 3 in flight, one thread: %.3f ms, %.0f GCUPS" % (G, t1 * 1e3, cells / t1 / 1e9))
     for T in (4, 8, 16):
         ctxs = [A.Context(0) for _ in range(T)]
         def work(k):
