@@ -440,6 +440,7 @@ void partition(accg_phmm_batch& b) {
   b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
   uint64_t kw[4][PHMM_MAX_K + 1] = {{0}};     // haplotype passes per (lanes per read: 8, 16, 32, 64; K)
   uint64_t n_form5 = 0, n_other = 0;          // ... in the five-operation form (whose jobs may go in pairs) / in the others
+#pragma omp parallel for schedule(dynamic, 4) num_threads(accg::host_threads()) if (b.regions.size() >= 32)
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     const Region& r = b.regions[ri];
     if (r.n_reads == 0 || r.n_haps == 0) continue;
@@ -468,10 +469,13 @@ void partition(accg_phmm_batch& b) {
       }
       i += take ? take : 1;                                    // (the first read always qualifies for its own group)
       groups[ri].push_back(Q);
-      kw[Q.lpp == 8 ? 0 : Q.lpp == 16 ? 1 : Q.lpp == 32 ? 2 : 3][Q.K] += (uint64_t)r.n_haps;
-      (Q.form == 5 && !Q.striped ? n_form5 : n_other) += (uint64_t)r.n_haps;
     }
   }
+  for (size_t ri = 0; ri < b.regions.size(); ri++)
+    for (const Group& Q : groups[ri]) {
+      kw[Q.lpp == 8 ? 0 : Q.lpp == 16 ? 1 : Q.lpp == 32 ? 2 : 3][Q.K] += (uint64_t)b.regions[ri].n_haps;
+      (Q.form == 5 && !Q.striped ? n_form5 : n_other) += (uint64_t)b.regions[ri].n_haps;
+    }
   // per-row records of the five-operation sweep: LPP * K per read of a wavefront that runs it (phmm_dev.h: PhmmRowRecs)
   for (const auto& gr : groups)
     for (const Group& Q : gr)
@@ -701,18 +705,20 @@ void partition(accg_phmm_batch& b) {
   }
   tpd = std::chrono::steady_clock::now();
   // one launch per K; inside a launch the longest jobs go first so the tail is short
-  // (sorted through an index: a Job is 120 bytes, the order is decided by a few of them)
-  std::vector<uint32_t> order(jobs.size());
-  std::iota(order.begin(), order.end(), 0u);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t xi, uint32_t yi) {
-    const Job &x = jobs[xi], &y = jobs[yi];
-    return x.striped != y.striped ? x.striped > y.striped : x.lpp != y.lpp ? x.lpp > y.lpp : x.K != y.K ? x.K > y.K : x.form != y.form ? x.form < y.form : x.wg != y.wg ? x.wg > y.wg
-                                                                                                                                : x.cost > y.cost;
-  });
+  // (sorted through (key, index) pairs: a Job is 120 bytes, the order is decided by a few of them)
+  std::vector<std::pair<uint64_t, uint32_t>> order(jobs.size());
+  for (size_t i = 0; i < jobs.size(); i++) {
+    const Job& x = jobs[i];
+    // descending: striped, lanes, K; ascending form; descending workgroup size and cost; ties in generation order
+    const uint64_t key = ((uint64_t)(x.striped ? 1 : 0) << 63) | ((uint64_t)(x.lpp & 127) << 56) | ((uint64_t)(x.K & 31) << 51) |
+                         ((uint64_t)(7 - x.form) << 48) | ((uint64_t)(x.wg & 3) << 46) | std::min<uint64_t>(x.cost, (1ull << 46) - 1);
+    order[i] = {~key, (uint32_t)i};
+  }
+  std::sort(order.begin(), order.end());
   {
     std::vector<Job> sorted;
     sorted.reserve(jobs.size());
-    for (uint32_t i : order) sorted.push_back(jobs[i]);
+    for (const auto& kv : order) sorted.push_back(jobs[kv.second]);
     jobs.swap(sorted);
   }
   b.work.clear();
@@ -969,12 +975,12 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   void* stage_v = nullptr;
   ACCG_HIP(ctx_stage(ctx, upload_bytes + 16, &stage_v));
   uint8_t* stage = (uint8_t*)stage_v;
-  roff = hoff = 0;
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n_regions >= 32)
   for (int i = 0; i < n_regions; i++) {
-    if (reads_bytes[i]) memcpy(stage + o_rblob + roff, reads_ser[i], reads_bytes[i]);
-    if (haps_bytes[i]) memcpy(stage + o_hblob + hoff, haps_ser[i], haps_bytes[i]);
-    roff += reads_bytes[i]; hoff += haps_bytes[i];
+    if (reads_bytes[i]) memcpy(stage + o_rblob + roffs[i], reads_ser[i], reads_bytes[i]);
+    if (haps_bytes[i]) memcpy(stage + o_hblob + hoffs[i], haps_ser[i], haps_bytes[i]);
   }
+  roff = roffs[n_regions]; hoff = hoffs[n_regions];
   memset(stage + o_rblob + roff, 0, 16); memset(stage + o_hblob + hoff, 0, 16);
   auto put = [&](size_t o, const auto& v) { if (!v.empty()) memcpy(stage + o, v.data(), vbytes(v)); };
   put(o_rd, b->rd); put(o_hp, b->hp); put(o_rd_out, b->rd_out); put(o_hp_local, b->hp_local);
