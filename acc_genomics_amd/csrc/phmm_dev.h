@@ -178,6 +178,10 @@ hipError_t phmm_launch_f32(int K, int lpp, bool strict, int form, bool striped, 
 // Xs is bounded by max(M) * F, F[r] = 1 + c[r] F[r-1]; M never exceeds INIT / H <= 2^120, so F <= 32 leaves a factor of 8 to
 // FLT_MAX.  Reads whose insertion qualities jump by more than ~7 dB from one base to the next push F up and stay in the
 // seven-operation form.
+// ... and the prepared five-operation sweep for several (lanes, K) classes in one launch: K in one of the windows {2..5}, {6..13},
+// 8 or 16 lanes per read, one workgroup size; lds_bytes = the largest phmm_lds_bytes of the classes
+hipError_t phmm_launch_f32_multi(int k_lo, int k_hi, size_t lds_bytes, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t s, int wg);
+inline int phmm_multi_window(int K) { return K >= 6 && K <= 13 ? 2 : K >= 2 && K <= 5 ? 1 : 0; }   // 0: no merged launch for this K
 constexpr float PHMM_X6_MAX_F = 32.f;
 // The five-operation form additionally keeps Y divided by the row's pMY (Ys <= max(M) / (1 - pYY)) and the diagonal term divided
 // by the consumer row's pMM: every pYY <= 31/32 and every pMM >= 1/16 keep both within a factor 32 / 16 of the unscaled values.

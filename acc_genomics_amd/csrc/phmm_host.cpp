@@ -214,7 +214,15 @@ namespace {
 struct Region { uint32_t read0, n_reads, hap0, n_haps; uint64_t out0; };
 // form: 7, 6 or 5 operations per cell; wg = 2: the work items come in pairs (same reads, two runs of haplotypes; the second may be
 // empty) that the fast kernel runs as one workgroup of two wavefronts sharing the dist table
-struct KLaunch { int K, lpp, form; bool striped; int wg; uint32_t work0, n_work; int stream_cap, haps_cap; uint64_t cost = 0; int aux = 0; };
+// 0: a class with a launch of its own; else (window of K, workgroup size) of the merged launch it can join
+inline int merge_class(int K, int lpp, int form, bool striped, int wg) {
+  if (striped || form != 5 || lpp * K <= 16 || (lpp != 8 && lpp != 16) || (wg != 1 && wg != 2)) return 0;
+  const int w = phmm_multi_window(K);
+  return w ? w * 4 + (wg & 3) : 0;
+}
+// k_hi != 0: a merged launch of the fast mode, the classes K..k_hi of both lane counts in one grid (phmm_launch_f32_multi)
+// (then K = smallest K, lpp = the lane count with the larger LDS request, wpc_min = the smallest occupancy of the classes in it)
+struct KLaunch { int K, lpp, form; bool striped; int wg; uint32_t work0, n_work; int stream_cap, haps_cap; uint64_t cost = 0; int aux = 0; int k_hi = 0; size_t lds = 0; int wpc_min = 0; };
 
 thread_local DevPool* tls_pool = nullptr;   // set for the duration of accg_phmm_batch_create
 struct PoolScope { DevPool* prev; explicit PoolScope(DevPool* p) : prev(tls_pool) { tls_pool = p; } ~PoolScope() { tls_pool = prev; } };
@@ -266,7 +274,8 @@ struct accg_phmm_batch {
   bool any_form5 = false;        // some launch runs the five-operation sweep: phmm_prepare_rows runs at the start of a fast pass
   std::vector<uint8_t> rd_form;  // per read: the cheapest form of the fast sweep it passes the range tests of: 5, 6 or 7 (phmm_dev.h)
   std::vector<PhmmWork> work;
-  std::vector<KLaunch> launches;
+  std::vector<KLaunch> launches;        // one per (lanes, K, form, workgroup size) class, in work-list order
+  std::vector<KLaunch> launches_fast;   // what the fast mode launches: the same list with the mergeable classes merged
   uint64_t pairs = 0, cells = 0, algo_bytes = 0;
   bool has_n = false;          // some haplotype contains an 'N': the dist table needs its fifth slab
   int force_wpc = 0;           // ACCG_PHMM_WPC: > 0 pins every launch to that many wavefronts per CU, < 0 pins nothing
@@ -709,9 +718,12 @@ void partition(accg_phmm_batch& b) {
   std::vector<std::pair<uint64_t, uint32_t>> order(jobs.size());
   for (size_t i = 0; i < jobs.size(); i++) {
     const Job& x = jobs[i];
-    // descending: striped, lanes, K; ascending form; descending workgroup size and cost; ties in generation order
-    const uint64_t key = ((uint64_t)(x.striped ? 1 : 0) << 63) | ((uint64_t)(x.lpp & 127) << 56) | ((uint64_t)(x.K & 31) << 51) |
-                         ((uint64_t)(7 - x.form) << 48) | ((uint64_t)(x.wg & 3) << 46) | std::min<uint64_t>(x.cost, (1ull << 46) - 1);
+    // descending: striped, merge class, lanes, K; ascending form; descending workgroup size and cost; ties in generation order.
+    // Merge class: the jobs of the prepared five-operation sweep whose K lies in one window of phmm_launch_f32_multi and that have the
+    // same workgroup size end up next to each other, ordered by lanes and K (= by rows per read), and can go out as ONE launch in fast mode.
+    const int mc = merge_class(x.K, x.lpp, x.form, x.striped, x.wg);
+    const uint64_t key = ((uint64_t)(x.striped ? 1 : 0) << 63) | ((uint64_t)(mc & 15) << 59) | ((uint64_t)(x.lpp & 63) << 53) | ((uint64_t)(x.K & 31) << 48) |
+                         ((uint64_t)(7 - x.form) << 45) | ((uint64_t)(x.wg & 3) << 43) | std::min<uint64_t>(x.cost, (1ull << 43) - 1);
     order[i] = {~key, (uint32_t)i};
   }
   std::sort(order.begin(), order.end());
@@ -736,21 +748,57 @@ void partition(accg_phmm_batch& b) {
     L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
     L.haps_cap = std::max(L.haps_cap, (int)std::max(jobs[i].w.n_haps, jobs[i].wg == 2 ? jobs[i].w2.n_haps : 0u));
   }
-  {   // which forked stream takes which launch: ACCG_PHMM_AUX = streams used (default all), ACCG_PHMM_LPT=1: longest first onto the
+  // The fast mode's list: consecutive classes of one merge class become one launch -- when the batch is small.  configs[3] shards,
+  // whole pass, separate launches -> one launch: 64 regions 1.06 -> 0.92 ms, 128 regions 1.75 -> 1.59, 256 regions 3.21 -> 2.92,
+  // 512 regions 5.92 -> 5.73.  At 1024 regions (190 k jobs) the sweep alone is 1.5 % faster merged but the whole pass measured 3 % slower
+  // on two boxes and 2 % faster on a third (one whose clocks are lower throughout), so large batches keep the separate launches: the
+  // rule is "at most 24 rounds of sixteen wavefronts per CU in the whole batch".  ACCG_PHMM_MERGE=0: never, =1: always.
+  {
+    const char* em = getenv("ACCG_PHMM_MERGE");          // read per batch: the tests build the same batch both ways
+    const int merge_knob = em ? atoi(em) : -1;
+    const bool merge_off = merge_knob == 0 || (merge_knob < 0 && b.work.size() > (size_t)24 * 16 * (size_t)std::max(b.ctx ? b.ctx->n_cu : 256, 1));
+    const int nchar = b.has_n ? 5 : 4;
+    int prev_mc = 0;
+    for (const KLaunch& l : b.launches) {
+      const int mc = merge_off ? 0 : merge_class(l.K, l.lpp, l.form, l.striped, l.wg);
+      if (mc && mc == prev_mc && !b.launches_fast.empty()) {
+        KLaunch& m = b.launches_fast.back();          // (lanes, K) descend along the work list
+        if (!m.k_hi) m.k_hi = m.K;
+        m.K = std::min(m.K, l.K); m.k_hi = std::max(m.k_hi, l.K); m.n_work += l.n_work; m.cost += l.cost;
+        m.stream_cap = std::max(m.stream_cap, l.stream_cap); m.haps_cap = std::max(m.haps_cap, l.haps_cap);
+      } else {
+        b.launches_fast.push_back(l);
+      }
+      prev_mc = mc;
+    }
+    // LDS request and occupancy of a merged launch: every class in it lays its block out with the launch's stream and haplotype caps
+    for (KLaunch& m : b.launches_fast) {
+      if (!m.k_hi) continue;
+      m.wpc_min = 32;
+      for (const KLaunch& l : b.launches) {
+        if (l.work0 < m.work0 || l.work0 >= m.work0 + m.n_work) continue;
+        m.lds = std::max(m.lds, phmm_lds_bytes(l.K, 4, nchar, m.stream_cap, m.haps_cap, l.lpp, true, false, l.wg));
+        m.wpc_min = std::min(m.wpc_min, waves_per_cu(l.K, nchar, m.stream_cap, m.haps_cap, l.lpp, false, 5, l.wg));
+      }
+    }
+  }
+  for (std::vector<KLaunch>* list : {&b.launches, &b.launches_fast}) {
+    std::vector<KLaunch>& launches = *list;
+    // which forked stream takes which launch: ACCG_PHMM_AUX = streams used (default all), ACCG_PHMM_LPT=1: longest first onto the
       // least loaded stream instead of round robin in class order
     const char* ea = getenv("ACCG_PHMM_AUX"); const char* el = getenv("ACCG_PHMM_LPT");
     const int n_aux = std::max(1, std::min((int)accg_ctx::N_AUX, ea ? atoi(ea) : (int)accg_ctx::N_AUX));
     if (el && el[0] == '1') {
-      std::vector<size_t> idx(b.launches.size());
+      std::vector<size_t> idx(launches.size());
       std::iota(idx.begin(), idx.end(), (size_t)0);
-      std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return b.launches[x].cost > b.launches[y].cost; });
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return launches[x].cost > launches[y].cost; });
       std::vector<uint64_t> load((size_t)n_aux, 0);
       for (size_t i : idx) {
         const int q = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        b.launches[i].aux = q; load[(size_t)q] += b.launches[i].cost;
+        launches[i].aux = q; load[(size_t)q] += launches[i].cost;
       }
     } else {
-      for (size_t i = 0; i < b.launches.size(); i++) b.launches[i].aux = (int)(i % (size_t)n_aux);
+      for (size_t i = 0; i < launches.size(); i++) launches[i].aux = (int)(i % (size_t)n_aux);
     }
   }
   if (trace_p) {
@@ -794,15 +842,17 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
   a.n_zero = (int)(state_words(*b) - state_counts(*b));
   a.clock_out = reinterpret_cast<unsigned long long*>(b->d_clock.p);
   if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
-  const bool fork = b->launches.size() > 1;          // several rows-per-lane classes: run them side by side
+  const std::vector<KLaunch>& launches = mode == ACCG_PHMM_STRICT ? b->launches : b->launches_fast;
+  const bool fork = launches.size() > 1;          // several rows-per-lane classes: run them side by side
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
-  for (const KLaunch& l : b->launches) {
+  for (const KLaunch& l : launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
     hipStream_t st = fork ? b->ctx->aux[l.aux] : b->ctx->stream;
     const bool strict_l = mode == ACCG_PHMM_STRICT || l.lpp * l.K <= 16;
+    const int k_top = l.k_hi ? l.k_hi : l.K;        // registers and LDS of a merged launch are those of its largest K
     // pinned occupancy: the launch asks for as much LDS as leaves exactly 8, 16 or 32 of its wavefronts on a CU
     const int wg = strict_l ? 1 : l.wg;         // a strict launch runs the items of a pair as two wavefronts of their own
-    const int natural = waves_per_cu(l.K, a.nchar, l.stream_cap, l.haps_cap, l.lpp, strict_l, l.form, wg);
+    const int natural = l.k_hi ? l.wpc_min : waves_per_cu(k_top, a.nchar, l.stream_cap, l.haps_cap, l.lpp, strict_l, l.form, wg);
     // (the compiled strict column is VOP3-heavy and does gain from a third wavefront per SIMD: any multiple of four for it)
     const int wpc = b->force_wpc > 0 ? std::min(b->force_wpc, natural) : b->force_wpc < 0 ? natural
                     : strict_l ? std::max(natural / 4 * 4, std::min(natural, 4)) : pinned_wpc(natural);
@@ -817,7 +867,11 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
     // as more than 1e-5 relative (a two-base read did, at 5.4e-6; tools/fuzz_phmm.py).  Long reads were suspected as well and
     // cleared: with them contracted the worst case over 1 500 random regions stays at that granularity, 2.4e-6.
     if (l.striped) a.lds_min = 0;                   // one long read per wavefront and a large LDS block: nothing to pin
-    ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, strict_l ? 7 : l.form, l.striped, a, l.work0, l.n_work, st, wg));
+    static const bool trace_l = getenv("ACCG_TRACE_LAUNCH") != nullptr;
+    if (trace_l) fprintf(stderr, "launch K %d..%d lanes %d form %d wg %d striped %d: %u jobs, stream_cap %d haps_cap %d, natural %d wpc %d lds_min %d fair %d aux %d\n",
+                         l.K, k_top, l.lpp, l.form, wg, (int)l.striped, l.n_work, l.stream_cap, l.haps_cap, natural, wpc, a.lds_min, a.fair, l.aux);
+    if (l.k_hi) ACCG_HIP(phmm_launch_f32_multi(l.K, l.k_hi, l.lds, a, l.work0, l.n_work, st, wg));
+    else ACCG_HIP(phmm_launch_f32(l.K, l.lpp, strict_l, strict_l ? 7 : l.form, l.striped, a, l.work0, l.n_work, st, wg));
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
   if (ev_end) ACCG_HIP(hipEventRecord(ev_end, b->ctx->stream));

@@ -14,6 +14,10 @@ hipError_t phmm_launch_f32_fast(int K, int lpp, int form, const PhmmArgs<float>&
 #endif
   return e;
 }
+// windows of K that one merged launch covers (phmm_kernel_multi): {2..5}, {6..13}, both lane counts
+hipError_t phmm_launch_f32_multi(int k_lo, int k_hi, size_t lds_bytes, const PhmmArgs<float>& a, uint32_t wb, uint32_t n, hipStream_t s, int wg) {
+  return wg == 2 ? launch_multi<2>(k_lo, k_hi, lds_bytes, a, wb, n, s) : launch_multi<1>(k_lo, k_hi, lds_bytes, a, wb, n, s);
+}
 hipError_t phmm_prepare_rows_launch(const PhmmArgs<float>& a, uint32_t n_reads, uint32_t* state, uint32_t state_words, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;
   hipLaunchKernelGGL(phmm_prepare_rows, dim3(n_reads), dim3(128), 0, s, a, n_reads, state, state_words);

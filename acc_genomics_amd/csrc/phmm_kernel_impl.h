@@ -1264,6 +1264,53 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(phmm_min
   }
 }
 
+// Several (lanes, K) classes in ONE launch (the prepared five-operation sweep only): the jobs of all classes with K in [KLO, KHI] and 8
+// or 16 lanes per read, each wavefront taking the sweep of its own shape (all reads of a wavefront share it: PhmmRowRecs::shape).
+// Why: every launch ends in a tail during which the chip runs empty, hardware queues take launches one at a time, and a batch of a
+// few hundred regions is nine launches of a few hundred to a few thousand jobs each (a 128-region configs[3] shard: the fp32 phase
+// spanned 1.33 ms for 0.86 ms of work).  Registers are those of KHI -- at most 123 up to K = 13, so the merged launch still runs
+// four wavefronts per SIMD.  The windows follow the occupancy classes: K <= 5 fits eight wavefronts per SIMD, K = 6..13 four to seven,
+// which the launches pin to four (phmm_host.cpp, pinned_wpc).
+template <int LPP, int K, int KHI, int W>
+__device__ __forceinline__ void phmm_multi_dispatch(const PhmmArgs<float>& a, uint32_t work_base, uint32_t job, int k) {
+  if (k == K) phmm_job<float, K, LPP, false, false, 5, false, W>(a, work_base, job);
+  else if constexpr (K < KHI) phmm_multi_dispatch<LPP, K + 1, KHI, W>(a, work_base, job, k);
+}
+template <int KLO, int KHI, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4))) void phmm_kernel_multi(PhmmArgs<float> a, uint32_t work_base, uint32_t n_work) {
+  static_assert(KLO >= 2 && KHI <= 13, "K classes within the 128-register budget");
+  if (a.zero_words && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < a.n_zero; i += 64 * W) a.zero_words[i] = 0u;
+  const uint32_t job = W > 1 ? blockIdx.x * W + (threadIdx.x >> 6) : blockIdx.x;
+  const bool probe = a.clock_out && blockIdx.x == 0 && (W == 1 || __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0);
+  unsigned c0 = 0, w0 = 0;
+  if (probe) { c0 = (unsigned)__builtin_amdgcn_s_memtime(); w0 = (unsigned)wall_clock64(); }
+  // (the first read of a work item always exists; with W = 2 both items of a pair list the same reads)
+  const uint32_t rid0 = __builtin_amdgcn_readfirstlane(a.work[work_base + job].read[0]);
+  const uint32_t shape = __builtin_amdgcn_readfirstlane(a.rec.shape[rid0]);
+  const int K = (int)(shape & 255u);
+  if ((shape >> 8) == 16u) phmm_multi_dispatch<16, KLO, KHI, W>(a, work_base, job, K);
+  else phmm_multi_dispatch<8, KLO, KHI, W>(a, work_base, job, K);
+  if (probe && threadIdx.x == 0) { a.clock_out[0] = (unsigned)__builtin_amdgcn_s_memtime() - c0; a.clock_out[1] = (unsigned)wall_clock64() - w0; }
+}
+// lds_bytes = the largest request of the merged classes (host: phmm_lds_bytes per class)
+template <int W>
+hipError_t launch_multi(int k_lo, int k_hi, size_t lds_bytes, const PhmmArgs<float>& a, uint32_t work_base, uint32_t n_work, hipStream_t st) {
+  if (n_work == 0) return hipSuccess;
+  if (n_work % W != 0) return hipErrorInvalidValue;
+  size_t lds = lds_bytes;
+  if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;
+  dim3 grid(n_work / W), block(64 * W);
+#define ACCG_MULTI(LO, HI)                                                                                     \
+  if (k_lo >= LO && k_hi <= HI) {                                                                              \
+    hipLaunchKernelGGL((phmm_kernel_multi<LO, HI, W>), grid, block, lds, st, a, work_base, n_work);             \
+    return hipGetLastError();                                                                                  \
+  }
+  ACCG_MULTI(6, 13) ACCG_MULTI(2, 5)
+#undef ACCG_MULTI
+  return hipErrorInvalidValue;
+}
+
 template <typename T, bool STRICT, bool RESCUE, int XF = 0, int W = 1>
 hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint32_t n_work, hipStream_t st, bool striped = false,
                   uint32_t grid_cap = PHMM_RESCUE_GRID) {

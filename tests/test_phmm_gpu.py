@@ -360,6 +360,37 @@ def test_full_size_c3_properties(ctx):
         assert np.max(np.abs(got - ol10) / np.abs(ol10)) < REL_TOL
 
 
+def test_merged_launch_equals_separate_launches(ctx, monkeypatch):
+    """Small batches send all (lanes, K) classes of the five-operation sweep out as one launch whose wavefronts pick their own shape
+    (phmm_kernel_multi); ACCG_PHMM_MERGE=0 keeps one launch per class.  Same bits both ways, equal to the model, in both K windows
+    (reads of 17..40 bases: K <= 5; up to 208: K 6..13) and with pairs of wavefronts (many haplotypes) as well as single ones."""
+    O = orc.oracle()
+    rng = synth.rng_for(340)
+    regs = [synth.make_region(rng, 40, 3, (17, 208), (40, 260), unrelated_frac=0.1),
+            synth.make_region(rng, 24, 14, (17, 60), (30, 120), n_frac=0.02),
+            synth.make_region(rng, 12, 33, (60, 150), (100, 300), unrelated_frac=0.2)]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]
+    got = {}
+    for knob in ("0", "1", None):
+        if knob is None:
+            monkeypatch.delenv("ACCG_PHMM_MERGE", raising=False)
+        else:
+            monkeypatch.setenv("ACCG_PHMM_MERGE", knob)
+        with A.PhmmBatch(ctx, ser) as b:
+            b.run(A.ACCG_PHMM_FAST)
+            raw, l10, cnt = b.results()
+        got[knob] = (raw.tobytes(), l10.tobytes(), cnt.rescued)
+    assert got["0"] == got["1"] == got[None]
+    raw = np.frombuffer(got["1"][0], np.float32)
+    k = 0
+    for reads, haps in regs:
+        for r in reads:
+            f = _read_form(O, r)
+            for h in haps:
+                assert np.float32(_model(O, r, h, f)).tobytes() == raw[k].tobytes(), k
+                k += 1
+
+
 def test_ring_equals_one_shot(ctx):
     """Regions in flight (accg_phmm_ring_*): the same bits as the blocking call, whatever the number of slots; a slot that has not
     been waited for refuses the next submit."""

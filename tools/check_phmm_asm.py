@@ -107,6 +107,8 @@ def main():
         # phmm_kernel<T, K, LPP, STRICT, RESCUE, XF (0 / 6 / 5: operations per cell of the fast sweep), STRIPED>
         m = re.search(r"phmm_kernelI([fd])Li(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])", name)
         asm_col = bool(m) and m.group(4) == "0" and m.group(7) == "0" and (m.group(1) == "f" or int(m.group(2)) <= 10)
+        # phmm_kernel_multi<KLO, KHI, W>: the same assembly sweeps of several shapes behind one branch each, laid out one after another
+        asm_col = asm_col or "phmm_kernel_multi" in name
         hand += asm_col
         if not asm_col:       # compiler-managed waits: its own s_waitcnt insertion follows the control flow, which this linear replay does not
             continue
