@@ -126,24 +126,24 @@ hipError_t phmm_prepare_rows_launch(const PhmmArgs<float>& a, uint32_t n_reads, 
 // ---- fp64 rescue planning (device side, no host round trip) -----------------------------------------
 // Reads that underflowed in fp32 against at least one haplotype are regrouped into new wavefront jobs so that
 // the fp64 pass only carries those reads (FalconPairHMM.cpp:636-652 redoes exactly the underflowed pairs).
-// (lanes per read, K) of the fp64 rescue kernels: 16 lanes x K for K in the list below, then (32,16) and (64,16).  Fine steps in K
-// matter here: an fp64 row costs twice the registers and ~1.8x the issue time of an fp32 one, so rows of padding are expensive.
-constexpr int PHMM_RESCUE_K16 = 11;
-constexpr int PHMM_RESCUE_CLASSES = PHMM_RESCUE_K16 + 3;      // ... (32,16), (64,16), (64,16) in stripes for reads of 1024 bases and more
-__host__ __device__ inline int phmm_rescue_k16(int i) {
-  constexpr int ks[PHMM_RESCUE_K16] = {2, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16};
-  return ks[i];
-}
+// (lanes per read, K) of the fp64 rescue kernels by rows (= read length + 1).  Up to 160 rows: 16 lanes per read and K up to 10 -- the
+// per-column work of a lane (hand-off, stream and table reads, loop) is spread over K rows, and 32 lanes x K <= 5 measured no faster
+// although it doubles the resident wavefronts (configs[3]: 3.0 against 2.9 ms).  Beyond that an fp64 lane runs out of registers (K = 12:
+// 412 with spills, one wavefront per SIMD), so longer reads are spread over 32 or 64 lanes with K between 5 and 8.
+constexpr int PHMM_RESCUE_CLASSES = 17;      // the last two: (64,16) up to 1024 rows, and (64,16) in stripes for reads of 1024 bases and more
 __host__ __device__ inline void phmm_rescue_shape(int cls, int* lpp, int* K) {
-  if (cls < PHMM_RESCUE_K16) { *lpp = 16; *K = phmm_rescue_k16(cls); }
-  else { *lpp = cls == PHMM_RESCUE_K16 ? 32 : 64; *K = 16; }
+  constexpr int lp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 64, 64, 64};
+  constexpr int ks[PHMM_RESCUE_CLASSES] = {2, 4, 5, 6, 7, 8, 9, 10, 6, 7, 8, 5, 6, 7, 8, 16, 16};
+  *lpp = lp[cls]; *K = ks[cls];
 }
-__host__ __device__ inline bool phmm_rescue_striped(int cls) { return cls == PHMM_RESCUE_K16 + 2; }
+__host__ __device__ inline bool phmm_rescue_striped(int cls) { return cls == PHMM_RESCUE_CLASSES - 1; }
 __host__ __device__ inline void phmm_rescue_class(uint32_t len, int* cls, int* lpp, int* K) {
   const uint32_t rows = len + 1;
-  int c = rows <= 1024 ? PHMM_RESCUE_K16 + 1 : PHMM_RESCUE_K16 + 2;
-  if (rows <= 256) { c = 0; while (16u * (uint32_t)phmm_rescue_k16(c) < rows) c++; }
-  else if (rows <= 512) c = PHMM_RESCUE_K16;
+  int c = PHMM_RESCUE_CLASSES - 1;
+  if (rows <= 1024) {
+    c = 0;
+    for (;;) { phmm_rescue_shape(c, lpp, K); if ((uint32_t)(*lpp * *K) >= rows) break; c++; }
+  }
   *cls = c;
   phmm_rescue_shape(c, lpp, K);
 }

@@ -1351,10 +1351,18 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
       ACCG_CASE(9, 16) ACCG_CASE(10, 16) ACCG_CASE(11, 16) ACCG_CASE(12, 16) ACCG_CASE(13, 16) ACCG_CASE(14, 16) ACCG_CASE(15, 16) ACCG_CASE(16, 16)
       default: return hipErrorInvalidValue;
     }
-  } else if (lpp == 32) {
-    switch (K) { ACCG_CASE(9, 32) ACCG_CASE(10, 32) ACCG_CASE(12, 32) ACCG_CASE(14, 32) ACCG_CASE(16, 32) default: return hipErrorInvalidValue; }
+  } else if (lpp == 32) {      // the sweep's classes for reads of 256 to 1022 bases (phmm_pick) / the rescue's (phmm_rescue_shape)
+    if constexpr (RESCUE) {
+      switch (K) { ACCG_CASE(6, 32) ACCG_CASE(7, 32) ACCG_CASE(8, 32) default: return hipErrorInvalidValue; }
+    } else {
+      switch (K) { ACCG_CASE(9, 32) ACCG_CASE(10, 32) ACCG_CASE(12, 32) ACCG_CASE(14, 32) ACCG_CASE(16, 32) default: return hipErrorInvalidValue; }
+    }
   } else {
-    switch (K) { ACCG_CASE(9, 64) ACCG_CASE(10, 64) ACCG_CASE(12, 64) ACCG_CASE(14, 64) ACCG_CASE(16, 64) default: return hipErrorInvalidValue; }
+    if constexpr (RESCUE) {
+      switch (K) { ACCG_CASE(5, 64) ACCG_CASE(6, 64) ACCG_CASE(7, 64) ACCG_CASE(8, 64) ACCG_CASE(16, 64) default: return hipErrorInvalidValue; }
+    } else {
+      switch (K) { ACCG_CASE(9, 64) ACCG_CASE(10, 64) ACCG_CASE(12, 64) ACCG_CASE(14, 64) ACCG_CASE(16, 64) default: return hipErrorInvalidValue; }
+    }
   }
   return hipGetLastError();
 #endif
