@@ -130,10 +130,10 @@ hipError_t phmm_prepare_rows_launch(const PhmmArgs<float>& a, uint32_t n_reads, 
 // per-column work of a lane (hand-off, stream and table reads, loop) is spread over K rows, and 32 lanes x K <= 5 measured no faster
 // although it doubles the resident wavefronts (configs[3]: 3.0 against 2.9 ms).  Beyond that an fp64 lane runs out of registers (K = 12:
 // 412 with spills, one wavefront per SIMD), so longer reads are spread over 32 or 64 lanes with K between 5 and 8.
-constexpr int PHMM_RESCUE_CLASSES = 17;      // the last two: (64,16) up to 1024 rows, and (64,16) in stripes for reads of 1024 bases and more
+constexpr int PHMM_RESCUE_CLASSES = 16;      // the last two: (64,16) up to 1024 rows, and (64,16) in stripes for reads of 1024 bases and more
 __host__ __device__ inline void phmm_rescue_shape(int cls, int* lpp, int* K) {
-  constexpr int lp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 64, 64, 64};
-  constexpr int ks[PHMM_RESCUE_CLASSES] = {2, 4, 5, 6, 7, 8, 9, 10, 6, 7, 8, 5, 6, 7, 8, 16, 16};
+  constexpr int lp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64};
+  constexpr int ks[PHMM_RESCUE_CLASSES] = {2, 4, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8, 16, 16};
   *lpp = lp[cls]; *K = ks[cls];
 }
 __host__ __device__ inline bool phmm_rescue_striped(int cls) { return cls == PHMM_RESCUE_CLASSES - 1; }

@@ -1353,7 +1353,7 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
     }
   } else if (lpp == 32) {      // the sweep's classes for reads of 256 to 1022 bases (phmm_pick) / the rescue's (phmm_rescue_shape)
     if constexpr (RESCUE) {
-      switch (K) { ACCG_CASE(6, 32) ACCG_CASE(7, 32) ACCG_CASE(8, 32) default: return hipErrorInvalidValue; }
+      switch (K) { ACCG_CASE(5, 32) ACCG_CASE(6, 32) ACCG_CASE(7, 32) ACCG_CASE(8, 32) default: return hipErrorInvalidValue; }
     } else {
       switch (K) { ACCG_CASE(9, 32) ACCG_CASE(10, 32) ACCG_CASE(12, 32) ACCG_CASE(14, 32) ACCG_CASE(16, 32) default: return hipErrorInvalidValue; }
     }
