@@ -160,6 +160,7 @@ struct PhmmPlanArgs {
   uint32_t* counts;               // jobs written per class
   uint32_t* flagged;              // scratch, one slot per read
   uint32_t class_off[PHMM_RESCUE_CLASSES + 1];
+  uint32_t pairs;                 // 1: every group's items come in pairs for workgroups of two wavefronts (an odd last one is followed by an empty item)
 };
 hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s);
 
@@ -191,7 +192,7 @@ constexpr float PHMM_X5_MAX_YY = 0.96875f, PHMM_X5_MIN_MM = 0.0625f;
 // strict: the operation order of compute_full_prob_baseline<double> (bit-exact with it); else the 7-op contraction with a redo in
 // that order of every job that produced a result below PHMM_F64_TINY
 hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s,
-                                  uint32_t grid_cap = PHMM_RESCUE_GRID_DEFAULT, bool form5 = false);
+                                  uint32_t grid_cap = PHMM_RESCUE_GRID_DEFAULT, bool form5 = false, int wg = 1);
 constexpr double PHMM_F64_TINY = 1e-280;      // x 2^1020 scaling included: 28 decades above the smallest normal double
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
 hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);

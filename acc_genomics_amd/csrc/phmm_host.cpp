@@ -644,7 +644,7 @@ void partition(accg_phmm_batch& b) {
       {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
         uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
         for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
-        for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)P.runs.size();
+        for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)((P.runs.size() + 1) / 2 * 2);   // (room for pairs)
       }
     }
     b.chunks_dev.resize(chunk0); b.chunk_stream16.resize(chunk0); b.chunk_stream_len.resize(chunk0);
@@ -884,6 +884,11 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   p.rd_out = b->d_rd_out.p; p.read_flag = b->d_state.p; p.jobs = b->d_rescue_jobs.p; p.counts = b->d_state.p + state_counts(*b);
   p.flagged = b->d_flagged.p;
   for (int c = 0; c <= PHMM_RESCUE_CLASSES; c++) p.class_off[c] = b->rescue_off[c];
+  // Pairs of items that share their dist table (fast mode): worth it when a region's haplotypes make two runs or more on average --
+  // with single runs every second wavefront would sit idle on its registers.  ACCG_PHMM_RESCUE_WG=1: never, =2: always.
+  static const int wg_knob = [] { const char* e = getenv("ACCG_PHMM_RESCUE_WG"); return e ? atoi(e) : 0; }();
+  const bool pairs = mode != ACCG_PHMM_STRICT && wg_knob != 1 && (wg_knob == 2 || b->chunks_dev.size() >= 2 * b->regions_dev.size());
+  p.pairs = pairs ? 1u : 0u;
   ACCG_HIP(phmm_rescue_plan_launch(p, (uint32_t)b->regions_dev.size(), s));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   a.work = b->d_rescue_jobs.p;
@@ -906,7 +911,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     a.redo_list = strict ? nullptr : b->d_redo.p + b->rescue_off[c];
     static const bool f5_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_FORM5"); return e && e[0] == '0'; }();   // A/B knob
     ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, strict, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st, PHMM_RESCUE_GRID_DEFAULT,
-                                    b->all_form5 && !f5_off));
+                                    b->all_form5 && !f5_off, pairs ? 2 : 1));
     if (!strict) {        // the jobs that launch listed (results next to the denormal range), in the reference's operation order
       PhmmArgs<double> r = a;
       r.job_count = a.redo_count; r.job_map = a.redo_list; r.redo_count = nullptr; r.redo_list = nullptr; r.is_redo = 1;

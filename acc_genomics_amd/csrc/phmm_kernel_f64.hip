@@ -11,7 +11,10 @@ hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>&
   return launch<double, true, false>(K, lpp, a, wb, n, s, striped);
 }
 hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t wb, uint32_t n, hipStream_t s,
-                                  uint32_t grid_cap, bool form5) {
+                                  uint32_t grid_cap, bool form5, int wg) {
+  // wg = 2 (fast mode, K <= 8): the items come in pairs that share their dist table (phmm_kernel)
+  if (wg == 2 && !strict && !striped && K <= 8)
+    return form5 ? launch<double, false, true, 5, 2>(K, lpp, a, wb, n, s, striped, grid_cap) : launch<double, false, true, 0, 2>(K, lpp, a, wb, n, s, striped, grid_cap);
   // form5 (fast mode, a batch all of whose reads pass the five-operation form's range tests, classes with the column in assembly):
   // five fp64 operations per cell instead of seven
   if (form5 && !strict && !striped && K <= PHMM_ASM_MAX_K_F64) return launch<double, false, true, 5>(K, lpp, a, wb, n, s, striped, grid_cap);

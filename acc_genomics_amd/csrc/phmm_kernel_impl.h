@@ -699,7 +699,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   constexpr int VN = Vec16<T>::N, QT = (K + VN - 1) / VN;
   constexpr bool COMPACT = phmm_is_compact((int)sizeof(T), STRICT, K) && !STRIPED;
   constexpr unsigned SLAB = phmm_slab_bytes(K, (int)sizeof(T), COMPACT);   // bytes between two bases' tables
-  static_assert(W == 1 || (!RESCUE && !STRIPED), "shared-table workgroups: the plain fp32 / fp64 passes only");
+  static_assert(W == 1 || !STRIPED, "shared-table workgroups: not for reads swept in stripes");
   unsigned char* tab = smem;
   const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   T* y0s = reinterpret_cast<T*>(smem + a.nchar * SLAB + (W > 1 ? wave * (int)phmm_wave_area_bytes((int)sizeof(T), a.stream_cap, a.haps_cap, LPP, STRIPED) : 0));
@@ -793,8 +793,8 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   }
   }
   if (RESCUE) {
-    if (n_haps == 0) return false;
-    if (lane == 0 && count_rescued) atomicAdd(a.n_rescued, (unsigned long long)n_flag);
+    if (W == 1 && n_haps == 0) return false;      // (in a pair this wavefront still writes its share of the table: it leaves behind the barrier)
+    if (lane == 0 && count_rescued && n_flag) atomicAdd(a.n_rescued, (unsigned long long)n_flag);
   }
   if (lane == 0) { bpos[n_haps] = pos; bpos[n_haps + 1] = 0x7FFFFFFF; y0s[n_haps] = T(0); hcol[n_haps] = 0; }
   if (!PRE) for (int i = lane; i < LPP + 20; i += 64) stream[LPP - 1 + pos + i] = i == 0 ? (uint8_t)a.nchar : (uint8_t)0;   // terminal bubble + drain + prefetch slack
@@ -1026,7 +1026,7 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   s.a_out = T(0); s.x_out = T(0); s.acc = T(0);
   if constexpr (W > 1) {
     __syncthreads();                                        // the other wavefront's slabs of the table
-    if (n_list == 0) return false;                          // the empty second job of an odd pair: it has done its share of the table
+    if (n_list == 0 || (RESCUE && n_haps == 0)) return false;   // the empty second job of an odd pair / nothing to rescue here: it has done its share of the table
   } else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's LDS writes (table, stream) before its own reads
     __builtin_amdgcn_wave_barrier();
@@ -1222,11 +1222,27 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
 
 // Four wavefronts per SIMD (128 registers) is what the five-operation sweep wants up to K = 13 (its loop takes 8 K + 16); the
 // prologue's batched loads would take a few more if the compiler were not told to stay within that.
-template <typename T, int K, int XF> constexpr int phmm_min_waves() { return (sizeof(T) == 4 && XF == 5 && K <= 13) ? 4 : 1; }
+// (fp64, five operations, K = 8 -- the largest rescue class: 171 registers left two wavefronts per SIMD, three fit from 168 down)
+template <typename T, int K, int XF> constexpr int phmm_min_waves() { return (sizeof(T) == 4 && XF == 5 && K <= 13) ? 4 : (sizeof(T) == 8 && XF == 5 && K == 8) ? 3 : 1; }
 template <typename T, int K, int LPP, bool STRICT, bool RESCUE, int XF = 0, bool STRIPED = false, int W = 1>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(phmm_min_waves<T, K, XF>()))) void phmm_kernel(PhmmArgs<T> a, uint32_t work_base, uint32_t n_work) {
   if (!RESCUE && a.zero_words && blockIdx.x == 0)          // see PhmmArgs::zero_words
     for (int i = threadIdx.x; i < a.n_zero; i += 64 * W) a.zero_words[i] = 0u;
+  if constexpr (W > 1 && RESCUE) {
+    // Rescue jobs in pairs (phmm_rescue_plan with PhmmPlanArgs::pairs): items 2 i and 2 i + 1 hold the same reads against two runs of
+    // haplotypes and share one dist table, which is most of a job's LDS -- an fp64 table of K = 8 is 20 KB, and one per wavefront
+    // left seven wavefronts on a CU.  Both wavefronts of a workgroup walk the pairs with the grid's stride.
+    const uint32_t n_dev = __builtin_amdgcn_readfirstlane(*a.job_count);
+    const uint32_t n = (n_dev < n_work ? n_dev : n_work) & ~1u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    for (uint32_t i = blockIdx.x * 2u; i < n; i += gridDim.x * 2u) {
+      const uint32_t job = i + wave;
+      const bool tiny = phmm_job<T, K, LPP, STRICT, RESCUE, XF, STRIPED, W>(a, work_base, job, !a.is_redo);
+      __syncthreads();                                       // the next pair rebuilds the table both wavefronts still read
+      if (!STRICT && tiny && a.redo_count && (threadIdx.x & 63) == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = job;
+    }
+    return;
+  }
   if constexpr (W > 1) {
     // (the launch's first wavefront times its own job on the shader clock and on the constant-rate wall clock: the clock the
     // card holds UNDER THIS KERNEL, which a bench line quotes next to the fraction of the issue roof)
@@ -1316,7 +1332,7 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
                   uint32_t grid_cap = PHMM_RESCUE_GRID) {
   if (n_work == 0) return hipSuccess;
   if (W > 1 && (striped || n_work % W != 0)) return hipErrorInvalidValue;
-  dim3 grid(RESCUE && a.job_count ? (n_work < grid_cap ? n_work : grid_cap) : n_work / W), block(64 * W);
+  dim3 grid(RESCUE && a.job_count ? (n_work / W < grid_cap ? n_work / W : grid_cap) : n_work / W), block(64 * W);
   if (striped) {      // reads of 1024 bases and more: 64 lanes x 16 rows per stripe, the generic column
     if (K != 16 || lpp != 64 || XF != 0) return hipErrorInvalidValue;
     size_t lds = phmm_lds_bytes(16, (int)sizeof(T), a.nchar, a.stream_cap, a.haps_cap, 64, false, true);
@@ -1465,13 +1481,15 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
     int cls, lpp, K;
     phmm_rescue_class(p.rd[out[i]].len, &cls, &lpp, &K);
     const uint32_t per = 64u / (uint32_t)lpp;
-    if (tid == 0) s_cnt = atomicAdd(&p.counts[cls], R.n_chunks);
+    // (pairs: an even number of items per group, the last one empty when the region has an odd number of haplotype runs)
+    const uint32_t n_items = p.pairs ? (R.n_chunks + 1u) & ~1u : R.n_chunks;
+    if (tid == 0) s_cnt = atomicAdd(&p.counts[cls], n_items);
     __syncthreads();
     const uint32_t base = s_cnt;
-    for (uint32_t c = tid; c < R.n_chunks; c += 256) {
+    for (uint32_t c = tid; c < n_items; c += 256) {
       PhmmWork w;
       for (uint32_t g = 0; g < PHMM_GROUPS; g++) w.read[g] = (g < per && i + g < nf) ? out[i + g] : PHMM_NO_READ;
-      w.hap_off = p.chunks[R.chunk0 + c].ids0; w.n_haps = p.chunks[R.chunk0 + c].n; w.pad_[0] = w.pad_[1] = 0;
+      w.hap_off = c < R.n_chunks ? p.chunks[R.chunk0 + c].ids0 : 0u; w.n_haps = c < R.n_chunks ? p.chunks[R.chunk0 + c].n : 0u; w.pad_[0] = w.pad_[1] = 0;
       if (base + c < p.class_off[cls + 1] - p.class_off[cls]) p.jobs[(size_t)p.class_off[cls] + base + c] = w;
     }
     __syncthreads();
