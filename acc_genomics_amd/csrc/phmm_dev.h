@@ -131,11 +131,31 @@ hipError_t phmm_prepare_rows_launch(const PhmmArgs<float>& a, uint32_t n_reads, 
 // although it doubles the resident wavefronts (configs[3]: 3.0 against 2.9 ms).  Beyond that an fp64 lane runs out of registers (K = 12:
 // 412 with spills, one wavefront per SIMD), so longer reads are spread over 32 or 64 lanes with K between 5 and 8.
 constexpr int PHMM_RESCUE_CLASSES = 16;      // the last two: (64,16) up to 1024 rows, and (64,16) in stripes for reads of 1024 bases and more
-__host__ __device__ inline void phmm_rescue_shape(int cls, int* lpp, int* K) {
+constexpr int phmm_rescue_lpp(int cls) {
   constexpr int lp[PHMM_RESCUE_CLASSES] = {16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64};
-  constexpr int ks[PHMM_RESCUE_CLASSES] = {2, 4, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8, 16, 16};
-  *lpp = lp[cls]; *K = ks[cls];
+  return lp[cls];
 }
+constexpr int phmm_rescue_k(int cls) {
+  constexpr int ks[PHMM_RESCUE_CLASSES] = {2, 4, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8, 16, 16};
+  return ks[cls];
+}
+__host__ __device__ inline void phmm_rescue_shape(int cls, int* lpp, int* K) { *lpp = phmm_rescue_lpp(cls); *K = phmm_rescue_k(cls); }
+// Merged rescue launches (fast mode, five-operation form): the classes with K <= 8 go out as two launches by register budget --
+// window 0: K <= 5 (at most 124 registers, four wavefronts per SIMD), window 1: K = 6..8 (at most 168, three) -- each walking its
+// classes' job arrays one after the other, the longest rows first.  PHMM_RESCUE_MERGED = classes covered (the two (64,16) ones keep
+// launches of their own).
+constexpr int PHMM_RESCUE_MERGED = PHMM_RESCUE_CLASSES - 2;
+constexpr int PHMM_RESCUE_WIN0_N = 5, PHMM_RESCUE_WIN1_N = 9;
+constexpr int phmm_rescue_win_class(int win, int i) {
+  constexpr int w0[PHMM_RESCUE_WIN0_N] = {10, 6, 2, 1, 0};
+  constexpr int w1[PHMM_RESCUE_WIN1_N] = {13, 12, 11, 9, 8, 7, 5, 4, 3};
+  return win == 0 ? w0[i] : w1[i];
+}
+constexpr int phmm_rescue_window(int cls) { return cls >= PHMM_RESCUE_MERGED ? -1 : phmm_rescue_k(cls) <= 5 ? 0 : 1; }
+struct PhmmRescueSet {
+  uint32_t off[PHMM_RESCUE_CLASSES + 1];   // class c's items at [off[c], off[c + 1]) of PhmmArgs::work
+  const uint32_t* counts;                  // items the planner wrote per class
+};
 __host__ __device__ inline bool phmm_rescue_striped(int cls) { return cls == PHMM_RESCUE_CLASSES - 1; }
 __host__ __device__ inline void phmm_rescue_class(uint32_t len, int* cls, int* lpp, int* K) {
   const uint32_t rows = len + 1;
@@ -193,6 +213,11 @@ constexpr float PHMM_X5_MAX_YY = 0.96875f, PHMM_X5_MIN_MM = 0.0625f;
 // that order of every job that produced a result below PHMM_F64_TINY
 hipError_t phmm_launch_rescue_f64(int K, int lpp, bool strict, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s,
                                   uint32_t grid_cap = PHMM_RESCUE_GRID_DEFAULT, bool form5 = false, int wg = 1);
+// one window of merged classes (a.work = the whole job array, a.redo_count / a.redo_list = ONE list of absolute item indices for all merged
+// classes); lds_bytes = the largest request among the window's classes that have jobs
+hipError_t phmm_launch_rescue_multi(int window, int wg, size_t lds_bytes, const PhmmArgs<double>& a, const PhmmRescueSet& rs, uint32_t grid, hipStream_t s);
+// the strict re-run of the items that list names, whatever their class (a.redo_count / a.redo_list as above)
+hipError_t phmm_launch_redo_multi(size_t lds_bytes, const PhmmArgs<double>& a, const PhmmRescueSet& rs, uint32_t grid, hipStream_t s);
 constexpr double PHMM_F64_TINY = 1e-280;      // x 2^1020 scaling included: 28 decades above the smallest normal double
 // fp64 over every pair of the jobs (tests, and FalconPairHMM's use_double=true path).
 hipError_t phmm_launch_f64(int K, int lpp, bool striped, const PhmmArgs<double>& a, uint32_t work_base, uint32_t n_work, hipStream_t s);

@@ -893,14 +893,43 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   a.work = b->d_rescue_jobs.p;
   a.stream_cap = b->rescue_stream_cap; a.haps_cap = b->rescue_haps_cap;
-  int n_cls = 0;
-  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) n_cls += b->rescue_bound[c] != 0;
-  const bool fork = n_cls > 1;
+  static const bool f5_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_FORM5"); return e && e[0] == '0'; }();   // A/B knobs
+  static const bool merge_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_MERGE"); return e && e[0] == '0'; }();
+  // Fast mode, every read in the five-operation form's range: the classes with K <= 8 go out as two launches by register budget
+  // (phmm_dev.h: PHMM_RESCUE_MERGED) and one strict re-run launch behind both, instead of two launches per class.
+  const bool merged = mode != ACCG_PHMM_STRICT && b->all_form5 && !f5_off && !merge_off;
+  const int wg = pairs ? 2 : 1;
+  uint64_t win_units[2] = {0, 0};
+  size_t win_lds[2] = {0, 0}, redo_lds = 0;
+  int n_launch = 0;
+  for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
+    if (!b->rescue_bound[c]) continue;
+    const int w = merged ? phmm_rescue_window(c) : -1;
+    if (w < 0) { n_launch++; continue; }
+    int lpp_c, k_c;
+    phmm_rescue_shape(c, &lpp_c, &k_c);
+    win_units[w] += b->rescue_bound[c] / (uint64_t)wg;
+    win_lds[w] = std::max(win_lds[w], phmm_lds_bytes(k_c, 8, a.nchar, a.stream_cap, a.haps_cap, lpp_c, true, false, wg));
+    redo_lds = std::max(redo_lds, phmm_lds_bytes(k_c, 8, a.nchar, a.stream_cap, a.haps_cap, lpp_c, false, false, 1));
+  }
+  n_launch += (win_units[0] != 0) + (win_units[1] != 0);
+  const bool fork = n_launch > 1;
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
   int rr = 0;
+  PhmmRescueSet rs;
+  for (int c = 0; c <= PHMM_RESCUE_CLASSES; c++) rs.off[c] = b->rescue_off[c];
+  rs.counts = b->d_state.p + state_counts(*b);
+  for (int w = 0; w < 2; w++) {
+    if (!win_units[w]) continue;
+    hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
+    a.job_count = nullptr; a.job_map = nullptr; a.is_redo = 0;
+    a.redo_count = b->d_state.p + state_redo(*b);          // one list for all merged classes: the first class's counter, the list from slot 0
+    a.redo_list = b->d_redo.p;
+    ACCG_HIP(phmm_launch_rescue_multi(w, wg, win_lds[w], a, rs, (uint32_t)std::min<uint64_t>(win_units[w], PHMM_RESCUE_GRID_DEFAULT), st));
+  }
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
     const uint32_t bound = (uint32_t)b->rescue_bound[c];       // < 2^32: checked at batch creation
-    if (!bound) continue;
+    if (!bound || (merged && phmm_rescue_window(c) >= 0)) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
     hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
@@ -909,9 +938,8 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     a.job_map = nullptr; a.is_redo = 0;
     a.redo_count = strict ? nullptr : b->d_state.p + state_redo(*b) + c;
     a.redo_list = strict ? nullptr : b->d_redo.p + b->rescue_off[c];
-    static const bool f5_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_FORM5"); return e && e[0] == '0'; }();   // A/B knob
     ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, strict, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st, PHMM_RESCUE_GRID_DEFAULT,
-                                    b->all_form5 && !f5_off, pairs ? 2 : 1));
+                                    b->all_form5 && !f5_off, wg));
     if (!strict) {        // the jobs that launch listed (results next to the denormal range), in the reference's operation order
       PhmmArgs<double> r = a;
       r.job_count = a.redo_count; r.job_map = a.redo_list; r.redo_count = nullptr; r.redo_list = nullptr; r.is_redo = 1;
@@ -919,6 +947,12 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     }
   }
   if (fork) ACCG_HIP(ctx_join(b->ctx));
+  if (win_units[0] || win_units[1]) {     // behind both windows: the items they listed, in the reference's operation order
+    PhmmArgs<double> r = a;
+    r.job_count = nullptr; r.job_map = nullptr; r.is_redo = 1;
+    r.redo_count = b->d_state.p + state_redo(*b); r.redo_list = b->d_redo.p;
+    ACCG_HIP(phmm_launch_redo_multi(redo_lds, r, rs, PHMM_REDO_GRID, s));
+  }
   return ACCG_OK;
 }
 

@@ -1385,6 +1385,86 @@ hipError_t launch(int K, int lpp, const PhmmArgs<T>& a, uint32_t work_base, uint
 #undef ACCG_CASE
 }
 
+// ---- merged rescue launches (phmm_dev.h: PHMM_RESCUE_MERGED) ----------------------------------------------------------------------
+template <int WIN, int I, int N, int W>
+__device__ __forceinline__ bool phmm_rescue_dispatch(const PhmmArgs<double>& a, const PhmmRescueSet& rs, int ci, uint32_t r, uint32_t wave, uint32_t* abs_item) {
+  constexpr int CLS = phmm_rescue_win_class(WIN, I);
+  if (ci == I) {
+    const uint32_t job = r * W + wave;
+    *abs_item = rs.off[CLS] + job;
+    return phmm_job<double, phmm_rescue_k(CLS), phmm_rescue_lpp(CLS), false, true, 5, false, W>(a, rs.off[CLS], job, true);
+  }
+  if constexpr (I + 1 < N) return phmm_rescue_dispatch<WIN, I + 1, N, W>(a, rs, ci, r, wave, abs_item);
+  return false;
+}
+template <int WIN, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WIN == 0 ? 4 : 3))) void phmm_rescue_multi(PhmmArgs<double> a, PhmmRescueSet rs) {
+  constexpr int N = WIN == 0 ? PHMM_RESCUE_WIN0_N : PHMM_RESCUE_WIN1_N;
+  // units (items, or pairs of items) per class of the window, in the window's order; never beyond a class's slots.  (Recomputed from the
+  // counts for every unit -- a handful of scalar loads -- rather than held across the sweeps, where every register counts.)
+  auto units_of = [&](int i) {
+    const int c = phmm_rescue_win_class(WIN, i);
+    const uint32_t cap = rs.off[c + 1] - rs.off[c], n = __builtin_amdgcn_readfirstlane(rs.counts[c]);
+    return (n < cap ? n : cap) / (uint32_t)W;
+  };
+  uint32_t total = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) total += units_of(i);
+  const uint32_t wave = W > 1 ? __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6)) : 0u;
+  for (uint32_t u = blockIdx.x; u < total; u += gridDim.x) {
+    uint32_t r = u;
+    int ci = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+      const uint32_t n_i = units_of(i);
+      if (ci == i && r >= n_i) { r -= n_i; ci = i + 1; }
+    }
+    uint32_t abs_item = 0;
+    const bool tiny = phmm_rescue_dispatch<WIN, 0, N, W>(a, rs, ci, r, wave, &abs_item);
+    if constexpr (W > 1) __syncthreads();                     // the next pair rebuilds the table both wavefronts still read
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    if (tiny && a.redo_count && (threadIdx.x & 63) == 0) a.redo_list[atomicAdd(a.redo_count, 1u)] = abs_item;
+  }
+}
+template <int C>
+__device__ __forceinline__ void phmm_redo_dispatch(const PhmmArgs<double>& a, const PhmmRescueSet& rs, uint32_t item) {
+  if (item >= rs.off[C] && item < rs.off[C + 1]) {
+    phmm_job<double, phmm_rescue_k(C), phmm_rescue_lpp(C), true, true, 0, false, 1>(a, 0u, item, false);
+    return;
+  }
+  if constexpr (C + 1 < PHMM_RESCUE_MERGED) phmm_redo_dispatch<C + 1>(a, rs, item);
+}
+template <int UNUSED = 0>      // (a template so that only the translation unit that launches it compiles it)
+__global__ __launch_bounds__(64) void phmm_redo_multi(PhmmArgs<double> a, PhmmRescueSet rs) {
+  const uint32_t n_dev = __builtin_amdgcn_readfirstlane(*a.redo_count), cap = rs.off[PHMM_RESCUE_MERGED];
+  const uint32_t n = n_dev < cap ? n_dev : cap;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    phmm_redo_dispatch<0>(a, rs, __builtin_amdgcn_readfirstlane(a.redo_list[i]));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+template <int UNUSED = 0>
+hipError_t launch_rescue_multi(int window, int wg, size_t lds, const PhmmArgs<double>& a, const PhmmRescueSet& rs, uint32_t grid, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  if ((window != 0 && window != 1) || (wg != 1 && wg != 2) || lds > 160 * 1024) return hipErrorInvalidValue;
+  if (window == 0) {
+    if (wg == 2) hipLaunchKernelGGL((phmm_rescue_multi<0, 2>), dim3(grid), dim3(128), lds, st, a, rs);
+    else hipLaunchKernelGGL((phmm_rescue_multi<0, 1>), dim3(grid), dim3(64), lds, st, a, rs);
+  } else {
+    if (wg == 2) hipLaunchKernelGGL((phmm_rescue_multi<1, 2>), dim3(grid), dim3(128), lds, st, a, rs);
+    else hipLaunchKernelGGL((phmm_rescue_multi<1, 1>), dim3(grid), dim3(64), lds, st, a, rs);
+  }
+  return hipGetLastError();
+}
+template <int UNUSED = 0>
+hipError_t launch_redo_multi(size_t lds, const PhmmArgs<double>& a, const PhmmRescueSet& rs, uint32_t grid, hipStream_t st) {
+  if (grid == 0) return hipSuccess;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((phmm_redo_multi<0>), dim3(grid), dim3(64), lds, st, a, rs);
+  return hipGetLastError();
+}
+
 // Per-row records of the five-operation sweep (PhmmRowRecs, phmm_dev.h): one block of 64 threads per read, once per pass.  The
 // arithmetic -- which float is multiplied with and divided by which, in which order -- is the prologue's own of the kernels that do
 // not use the records (phmm_job, the X5 block), so both give the same bits (oracle model: orc_phmm_forward_f32_fma5).

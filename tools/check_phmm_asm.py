@@ -9,7 +9,7 @@
     data (or be overwritten when the load lands).  The check replays every phmm kernel linearly with the hardware's rule (LDS
     operations return in order).
 
-usage: tools/check_phmm_asm.py [object files]     default: build/phmm_kernel_fast.o build/phmm_kernel_f64.o     (exit status 0 = clean)"""
+usage: tools/check_phmm_asm.py [object files]     default: build/phmm_kernel_fast.o build/phmm_kernel_f64.o build/phmm_kernel_f64_multi.o     (exit status 0 = clean)"""
 import os
 import re
 import subprocess
@@ -97,10 +97,10 @@ def check_kernel(name, ins):
 
 
 def main():
-    objs = sys.argv[1:] or [os.path.join(ROOT, "acc_genomics_amd", "csrc", "build", n) for n in ("phmm_kernel_fast.o", "phmm_kernel_f64.o")]
+    objs = sys.argv[1:] or [os.path.join(ROOT, "acc_genomics_amd", "csrc", "build", n) for n in ("phmm_kernel_fast.o", "phmm_kernel_f64.o", "phmm_kernel_f64_multi.o")]
     bad, seen, hand = 0, 0, 0
     for name, body in (kb for obj in objs for kb in kernels(disassemble(obj))):
-        if "phmm_kernel" not in name:
+        if "phmm_kernel" not in name and "phmm_rescue_multi" not in name:
             continue
         ins = [l.split("//")[0].strip() for l in body if l and not l.startswith(";")]
         seen += 1
@@ -108,7 +108,7 @@ def main():
         m = re.search(r"phmm_kernelI([fd])Li(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])", name)
         asm_col = bool(m) and m.group(4) == "0" and m.group(7) == "0" and (m.group(1) == "f" or int(m.group(2)) <= 10)
         # phmm_kernel_multi<KLO, KHI, W>: the same assembly sweeps of several shapes behind one branch each, laid out one after another
-        asm_col = asm_col or "phmm_kernel_multi" in name
+        asm_col = asm_col or "phmm_kernel_multi" in name or "phmm_rescue_multi" in name
         hand += asm_col
         if not asm_col:       # compiler-managed waits: its own s_waitcnt insertion follows the control flow, which this linear replay does not
             continue
