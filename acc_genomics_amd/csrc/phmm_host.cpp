@@ -886,15 +886,16 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   for (int c = 0; c <= PHMM_RESCUE_CLASSES; c++) p.class_off[c] = b->rescue_off[c];
   // Pairs of items that share their dist table (fast mode): worth it when a region's haplotypes make two runs or more on average --
   // with single runs every second wavefront would sit idle on its registers.  ACCG_PHMM_RESCUE_WG=1: never, =2: always.
-  static const int wg_knob = [] { const char* e = getenv("ACCG_PHMM_RESCUE_WG"); return e ? atoi(e) : 0; }();
+  // (knobs read per pass: the tests run one batch every way)
+  const int wg_knob = [] { const char* e = getenv("ACCG_PHMM_RESCUE_WG"); return e ? atoi(e) : 0; }();
   const bool pairs = mode != ACCG_PHMM_STRICT && wg_knob != 1 && (wg_knob == 2 || b->chunks_dev.size() >= 2 * b->regions_dev.size());
   p.pairs = pairs ? 1u : 0u;
   ACCG_HIP(phmm_rescue_plan_launch(p, (uint32_t)b->regions_dev.size(), s));
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   a.work = b->d_rescue_jobs.p;
   a.stream_cap = b->rescue_stream_cap; a.haps_cap = b->rescue_haps_cap;
-  static const bool f5_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_FORM5"); return e && e[0] == '0'; }();   // A/B knobs
-  static const bool merge_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_MERGE"); return e && e[0] == '0'; }();
+  const bool f5_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_FORM5"); return e && e[0] == '0'; }();   // A/B knobs
+  const bool merge_off = [] { const char* e = getenv("ACCG_PHMM_RESCUE_MERGE"); return e && e[0] == '0'; }();
   // Fast mode, every read in the five-operation form's range: the classes with K <= 8 go out as two launches by register budget
   // (phmm_dev.h: PHMM_RESCUE_MERGED) and one strict re-run launch behind both, instead of two launches per class.
   const bool merged = mode != ACCG_PHMM_STRICT && b->all_form5 && !f5_off && !merge_off;

@@ -391,6 +391,35 @@ def test_merged_launch_equals_separate_launches(ctx, monkeypatch):
                 k += 1
 
 
+def test_rescue_launch_shapes_agree(ctx, monkeypatch):
+    """The fp64 rescue of the fast mode every way it can be launched -- one launch per class or the two merged windows, items singly or
+    in pairs that share their table, five or seven operations per cell -- on regions whose reads span every rescue class up to 500
+    bases: the same bits (the contracted forms differ from each other by less than the tolerance, the pairs / merged variants of one
+    form not at all), the same rescued count, and within tolerance of the strict mode."""
+    rng = synth.rng_for(350)
+    regs = [synth.make_region(rng, 64, 5, (20, 170), (60, 400), unrelated_frac=0.5),
+            synth.make_region(rng, 24, 7, (150, 500), (300, 700), unrelated_frac=0.6),
+            synth.make_region(rng, 9, 1, (60, 160), (200, 300), unrelated_frac=0.7)]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]
+    with A.PhmmBatch(ctx, ser) as b:
+        b.run(A.ACCG_PHMM_STRICT)
+        _, want, cs = b.results()
+        got = {}
+        for form5 in ("1", "0"):
+            for wg in ("1", "2"):
+                for merge in ("0", "1"):
+                    monkeypatch.setenv("ACCG_PHMM_RESCUE_FORM5", form5)
+                    monkeypatch.setenv("ACCG_PHMM_RESCUE_WG", wg)
+                    monkeypatch.setenv("ACCG_PHMM_RESCUE_MERGE", merge)
+                    b.run(A.ACCG_PHMM_FAST)
+                    raw, l10, cnt = b.results()
+                    assert cnt.rescued == cs.rescued and cs.rescued > 100
+                    assert np.max(np.abs(l10 - want) / np.abs(want)) < REL_TOL
+                    got[(form5, wg, merge)] = l10.tobytes()
+        for form5 in ("1", "0"):
+            assert len({got[(form5, wg, merge)] for wg in ("1", "2") for merge in ("0", "1")}) == 1
+
+
 def test_ring_equals_one_shot(ctx):
     """Regions in flight (accg_phmm_ring_*): the same bits as the blocking call, whatever the number of slots; a slot that has not
     been waited for refuses the next submit."""
