@@ -3,6 +3,7 @@
 // prepare()/compute() (pairhmm/task/xlnx/PairHMMTask.cpp:27-143) and the pair loop + post-process of
 // FalconPairHMM::computePairhmmAVX (pairhmm/xlnx/host/FalconPairHMM.cpp:69-95).
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <sched.h>
 #include <stdio.h>
@@ -13,6 +14,8 @@
 #include <map>
 #include <memory>
 #include <numeric>
+#include <condition_variable>
+#include <thread>
 #include "accg_internal.h"
 
 using namespace accg;
@@ -55,6 +58,10 @@ extern "C" int accg_init(int device, accg_ctx** out) {
   ACCG_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ACCG_ERR_NO_DEVICE;   // code objects are gfx950 only
   ACCG_HIP(hipSetDevice(device));
+  // The host loops' OpenMP threads go to sleep a millisecond after a parallel region instead of libomp's 200 ms of spinning: under a
+  // CPU quota (a container's share of a large host) spinners eat the quota the working threads need (a threaded ring next to a
+  // 16-thread team measured 30 ms for a stream that takes 7).  KMP_BLOCKTIME in the environment wins.
+  if (!getenv("KMP_BLOCKTIME")) kmp_set_blocktime(1);
   // a failure below hands the half-built context to accg_shutdown (streams, events, tables made so far are released)
   struct Guard { accg_ctx* c; ~Guard() { if (c) accg_shutdown(c); } } guard{new accg_ctx};
   accg_ctx* c = guard.c;
@@ -108,7 +115,13 @@ constexpr size_t POOL_MAX_BLOCK = 256ull << 20, POOL_MAX_CACHED = 4ull << 30;
 size_t pool_round(size_t b) {
   if (b <= 256) return 256;
   if (b <= (1u << 20)) { size_t r = 256; while (r < b) r <<= 1; return r; }
-  return (b + (1u << 20) - 1) >> 20 << 20;
+  // above 1 MiB: quarter-octave steps (at most 25 % over).  Batches of a stream differ by a few per cent in size; with 1 MiB steps every
+  // new largest one missed the cache, and a hipMalloc under load waits for the device to go idle (measured: 5 to 10 ms, and it
+  // holds up every other thread's allocation meanwhile).
+  size_t p2 = (size_t)1 << 20;
+  while (p2 * 2 < b) p2 <<= 1;                 // p2 < b <= 2 p2
+  const size_t q = p2 / 4;
+  return p2 + (b - p2 + q - 1) / q * q;
 }
 }  // namespace
 hipError_t DevPool::get(size_t bytes, void** p) {
@@ -148,7 +161,9 @@ void DevPool::drain() {
   { std::lock_guard<std::mutex> g(mu); f.swap(free_); cached = 0; }
   for (auto& kv : f) hipFree(kv.second);
 }
+thread_local int tls_host_threads = 0;      // a ring worker's share of the host threads (accg_phmm_ring_create_threaded)
 int host_threads() {
+  if (tls_host_threads > 0) return tls_host_threads;
   static const int n = [] {
     if (const char* e = getenv("ACCG_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
     int cpus = 1;
@@ -309,6 +324,7 @@ struct accg_phmm_batch {
   // One pass = memset + a launch per (lanes, K) class on forked streams + rescue plan + the rescue classes and their strict
   // re-runs: captured once per arithmetic mode into a graph and replayed (every argument is fixed at batch creation).
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  bool results_late = false;     // ring: the downloads are queued by results_finish, not behind the kernels
   bool graph_off = false;        // capture failed once, or ACCG_PHMM_GRAPH=0: plain stream launches
 };
 
@@ -320,17 +336,32 @@ namespace {
 int phmm_read_form(const uint8_t* p, int len) {
   const HostTables& t = host_tables();
   const uint8_t *qi = p + 2 * (size_t)len, *qd = p + 3 * (size_t)len, *qc = p + 4 * (size_t)len;
-  double F = 1.0;
-  for (int r = 1; r < len; r++) {              // PHMM_X6_MAX_F: Xs = X / pMX stays within F x max(M)
-    const double c = (double)t.ph_f[qc[r] & 127] * (double)t.ph_f[qi[r - 1] & 127] / (double)t.ph_f[qi[r] & 127];
-    F = 1.0 + c * F;
-    if (!(F <= (double)PHMM_X6_MAX_F)) return 7;
+  // PHMM_X6_MAX_F: Xs = X / pMX stays within F x max(M), F[r] = 1 + c[r] F[r - 1], c[r] = ph[qc[r]] ph[qi[r - 1]] / ph[qi[r]] =
+  // 10^-((qc[r] + qi[r - 1] - qi[r]) / 10).  When that exponent is at least 0.1 everywhere, every c is at most 0.7944 whatever the
+  // tables' last bits and F stays below 4.9: no need for the sum itself (the common case: a byte loop the compiler vectorises, where
+  // the sum is a chain of dependent divisions -- half of a batch's parse time).
+  int slack = 1;
+  for (int r = 1; r < len; r++) slack &= (int)((qc[r] & 127) + (qi[r - 1] & 127) >= (qi[r] & 127) + 1);
+  if (!slack) {
+    double F = 1.0;
+    for (int r = 1; r < len; r++) {
+      const double c = (double)t.ph_f[qc[r] & 127] * (double)t.ph_f[qi[r - 1] & 127] / (double)t.ph_f[qi[r] & 127];
+      F = 1.0 + c * F;
+      if (!(F <= (double)PHMM_X6_MAX_F)) return 7;
+    }
   }
-  for (int r = 0; r < len; r++) {              // PHMM_X5_*: Ys = Y / pMY and the term / pMM
-    const int i = qi[r] & 127, d = qd[r] & 127, lo = i < d ? i : d, hi = i < d ? d : i;
-    if (!(t.m2m_f[((hi * (hi + 1)) >> 1) + lo] >= PHMM_X5_MIN_MM) || !(t.ph_f[qc[r] & 127] <= PHMM_X5_MAX_YY)) return 6;
-  }
-  return 5;
+  // PHMM_X5_*: Ys = Y / pMY and the term / pMM -- the two comparisons on the tables' own floats, tabulated once per quality (pair)
+  struct Ok { uint8_t c[128], mm[128 * 128]; };
+  static const Ok ok = [&] {
+    Ok o;
+    for (int q = 0; q < 128; q++) o.c[q] = t.ph_f[q] <= PHMM_X5_MAX_YY;
+    for (int i = 0; i < 128; i++)
+      for (int d = 0; d < 128; d++) { const int lo = i < d ? i : d, hi = i < d ? d : i; o.mm[i * 128 + d] = t.m2m_f[((hi * (hi + 1)) >> 1) + lo] >= PHMM_X5_MIN_MM; }
+    return o;
+  }();
+  int all = 1;
+  for (int r = 0; r < len; r++) all &= ok.c[qc[r] & 127] & ok.mm[(qi[r] & 127) * 128 + (qd[r] & 127)];
+  return all ? 5 : 6;
 }
 
 int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, std::vector<uint8_t>& form) {
@@ -1048,6 +1079,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const size_t o_state = take((sw + (sw & 1)) * sizeof(uint32_t) + (b->pairs + 1) * sizeof(float));
   const size_t o_out = o_state + (sw + (sw & 1)) * sizeof(uint32_t);
   if ((st = b->d_arena.alloc(off + 256)) != ACCG_OK) return st;
+  const auto tq1 = std::chrono::steady_clock::now();
   uint8_t* base = b->d_arena.p;
   b->d_rblob.place(base, o_rblob, roff + 16); b->d_hblob.place(base, o_hblob, hoff + 16);
   b->d_rd.place(base, o_rd, b->rd.size()); b->d_hp.place(base, o_hp, b->hp.size());
@@ -1068,6 +1100,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   if (state_nresc(*b) * sizeof(uint32_t) + o_state != b->res_off) return ACCG_ERR_BAD_ARG;   // layout invariant of the single D2H
   void* stage_v = nullptr;
   ACCG_HIP(ctx_stage(ctx, upload_bytes + 16, &stage_v));
+  const auto tq2 = std::chrono::steady_clock::now();
   uint8_t* stage = (uint8_t*)stage_v;
 #pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n_regions >= 32)
   for (int i = 0; i < n_regions; i++) {
@@ -1086,14 +1119,20 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   put(o_row0, b->rd_row0); put(o_shape, b->rd_shape); put(o_streams, b->streams);
   memset(stage + o_streams + b->streams.size(), 0, 16);
   b->hp_ptr.clear(); b->hp_ptr.shrink_to_fit();            // the caller's blobs are not ours beyond this call
+  const auto tq3 = std::chrono::steady_clock::now();
   if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
+  const auto tq4 = std::chrono::steady_clock::now();
   ACCG_HIP(hipMemsetAsync(base + o_out64, 0, (o_out - o_out64) + (b->pairs + 1) * sizeof(float), s));   // out64, state, out
   if (b->any_form5 && b->n_rows) {       // the per-row records of the five-operation sweep (phmm_dev.h: PhmmRowRecs), from the uploaded reads
     const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, ctx->tab_f);
     ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), nullptr, 0, s));
   }
   if (!ctx->async_create) ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
-  if (getenv("ACCG_TRACE")) fprintf(stderr, "accg_phmm_batch_create: partition %.0f us, arena + upload %.0f us\n", std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count());
+  if (getenv("ACCG_TRACE")) {
+    auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+    fprintf(stderr, "accg_phmm_batch_create: partition %.0f us, arena + upload %.0f us (arena of %zu MiB %.0f, staging %.0f, fill %.0f, copy of %zu KiB queued %.0f, clear + row records queued %.0f)\n",
+            us(tp0, tp1), us(tp1, std::chrono::steady_clock::now()), (off + 256) >> 20, us(tp1, tq1), us(tq1, tq2), us(tq2, tq3), upload_bytes >> 10, us(tq3, tq4), us(tq4, std::chrono::steady_clock::now()));
+  }
   sync_on_error.dismiss();
   *out = b.release();
   return ACCG_OK;
@@ -1241,10 +1280,16 @@ namespace {
 // results of a pass in two halves for the ring: the device-to-host copies queued behind the kernels (both result arrays, always),
 // and the host half -- wait, log10 (same libm as the reference) -- when the caller comes for them
 size_t results_stage_bytes(uint64_t pairs) { return (sizeof(unsigned long long) + pairs * sizeof(float) + 7) / 8 * 8 + pairs * sizeof(double) + 64; }
-int results_enqueue(accg_phmm_batch* b) {
+// The downloads of a ticket: queued behind its kernels at once (plain ring: one caller thread, nothing else submits meanwhile), or
+// -- threaded ring, `late` -- only when the kernels have finished: a copy that sits in a DMA queue waiting for a kernel blocks the
+// NEXT copy submitted to that queue, another slot's upload, inside hipMemcpyAsync on that slot's worker (measured: creations of
+// 1.7 ms took 7 to 11 ms while the device worked through the tickets ahead).
+int results_enqueue(accg_phmm_batch* b, bool late) {
   const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
   void* stage_v = nullptr;
   ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));      // (sized by the submitter before the upload: no reallocation here)
+  b->results_late = late;
+  if (late) return ACCG_OK;
   uint8_t* stage = (uint8_t*)stage_v;
   ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
   if (n) ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
@@ -1253,14 +1298,24 @@ int results_enqueue(accg_phmm_batch* b) {
 int results_finish(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* cnt) {
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
-  const uint8_t* stage = (const uint8_t*)b->ctx->h_stage;
+  uint8_t* stage = (uint8_t*)b->ctx->h_stage;
+  if (b->results_late) {
+    ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
+    ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  }
   unsigned long long nresc = 0;
   memcpy(&nresc, stage, sizeof nresc);
   const float* raw = (const float*)(stage + sizeof nresc);
   const double* r64 = (const double*)(stage + head_al);
   if (out_raw && n) memcpy(out_raw, raw, n * sizeof(float));
   if (out_log10 && n) {
+    if (nresc && b->results_late) {              // the fp64 values only when something was rescued
+      ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+      ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+    }
     const HostTables& t = host_tables();
+    // (a log10f per pair is 10 ns: half a millisecond for a ticket of 32 configs[3] regions on one thread)
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n >= 16384 && accg::host_threads() > 1)
     for (size_t i = 0; i < n; i++)             // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
       out_log10[i] = raw[i] < PHMM_MIN_ACCEPTED ? log10(r64[i]) - t.log10_init_d : (double)(log10f(raw[i]) - t.log10_init_f);
   }
@@ -1369,13 +1424,66 @@ extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t rea
 // downloads without waiting; accg_phmm_ring_wait fetches the results of the oldest one -- while region i computes, region i + 1
 // is being parsed and region i - 1 read back.  compute_fpga / FalconPairHMM::computePairhmm keep their blocking signatures on
 // top of accg_phmm_region (pairhmm/host/PairHMMFpga.h:16-20); a caller that owns the loop over active regions uses the ring.
+// A threaded ring (accg_phmm_ring_create_threaded) moves that host half off the caller too: submit hands the pointers to the slot's
+// worker thread and returns, so the host halves of up to `slots` tickets run side by side, each on ONE host thread (a stream of
+// configs[3] regions is bound by exactly that: some 60 us of parsing, job sizing and staging per region on one thread against 11 us
+// of device time; eight workers keep the device busy).
+struct RingSlot {
+  std::thread th;                 // lives as long as the ring
+  std::mutex mu;
+  std::condition_variable cv;
+  bool has_work = false, done = false, quit = false;
+  int n_regions = 0, mode = 0;
+  uint64_t pairs = 0; size_t blob = 0;
+  int status = ACCG_OK;
+  std::string err;
+  std::vector<const void*> rs, hs;
+  std::vector<size_t> rb, hb;
+  std::vector<float> raw;         // the ticket's results, finished (download waited for, log10 taken) by the worker
+  std::vector<double> l10;
+  accg_counters cnt{};
+  bool busy = false;              // a ticket is outstanding (caller's side)
+};
 struct accg_phmm_ring {
   std::vector<accg_ctx*> ctx;
   std::vector<accg_phmm_batch*> batch;       // per slot: the region in flight (null: free)
+  std::vector<std::unique_ptr<RingSlot>> slot;   // threaded rings
+  bool threaded = false;
   uint64_t next_ticket = 0;
 };
 
-extern "C" int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out) {
+static int ring_submit_body(accg_phmm_ring* r, size_t slot, int n_regions, const void* const* reads_ser, const size_t* reads_bytes,
+                            const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t pairs, size_t blob);
+static void ring_worker(accg_phmm_ring* r, size_t slot) {
+  RingSlot& S = *r->slot[slot];
+  tls_host_threads = 1;                       // no team of its own: the workers ARE the host's parallelism
+  for (;;) {
+    std::unique_lock<std::mutex> lk(S.mu);
+    S.cv.wait(lk, [&] { return S.has_work || S.quit; });
+    if (S.quit) return;
+    S.has_work = false;
+    lk.unlock();
+    int st = ring_submit_body(r, slot, S.n_regions, S.rs.data(), S.rb.data(), S.hs.data(), S.hb.data(), S.mode, S.pairs, S.blob);
+    if (st == ACCG_OK) {        // ... and the device half's end: wait for the downloads, take the log10 -- off the caller's thread too
+      accg_phmm_batch* b = r->batch[slot];
+      S.raw.resize(b->pairs); S.l10.resize(b->pairs);
+      const auto tf0 = std::chrono::steady_clock::now();
+      st = results_finish(b, S.raw.data(), S.l10.data(), &S.cnt);
+      const auto tf1 = std::chrono::steady_clock::now();
+      accg_phmm_batch_destroy(b);
+      if (getenv("ACCG_TRACE")) fprintf(stderr, "ring slot %zu: finish %.0f us, destroy %.0f us\n", slot, std::chrono::duration<double, std::micro>(tf1 - tf0).count(),
+                                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf1).count());
+      r->batch[slot] = nullptr;
+    }
+    lk.lock();
+    S.status = st;
+    if (st != ACCG_OK) S.err = accg_last_hip_error();
+    S.done = true;
+    lk.unlock();
+    S.cv.notify_all();
+  }
+}
+static int ring_create(accg_ctx* ctx, int slots, bool threaded, accg_phmm_ring** out) {
   if (!ctx) return ACCG_ERR_NOT_INITIALISED;
   if (!out || slots < 1 || slots > 64) return ACCG_ERR_BAD_ARG;
   *out = nullptr;
@@ -1388,7 +1496,48 @@ extern "C" int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** 
     r->ctx.push_back(c);
   }
   r->batch.assign((size_t)slots, nullptr);
+  r->threaded = threaded;
+  if (threaded) {
+    accg_phmm_ring* rp = r.get();
+    for (int i = 0; i < slots; i++) r->slot.emplace_back(new RingSlot);
+    try {
+      for (int i = 0; i < slots; i++) r->slot[(size_t)i]->th = std::thread(ring_worker, rp, (size_t)i);
+    } catch (...) {
+      accg_phmm_ring_destroy(r.release());
+      return ACCG_ERR_BAD_ARG;
+    }
+  }
   *out = r.release();
+  return ACCG_OK;
+}
+extern "C" int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out) { return ring_create(ctx, slots, false, out); }
+extern "C" int accg_phmm_ring_create_threaded(accg_ctx* ctx, int slots, accg_phmm_ring** out) { return ring_create(ctx, slots, true, out); }
+
+// the host half of a ticket and everything it queues: on the caller's thread (plain ring) or on the slot's worker
+static int ring_submit_body(accg_phmm_ring* r, size_t slot, int n_regions, const void* const* reads_ser, const size_t* reads_bytes,
+                            const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t pairs, size_t blob) {
+  accg_ctx* c = r->ctx[slot];
+  ACCG_HIP(hipSetDevice(c->device));
+  // pinned staging large enough for the upload AND the downloads, before anything is queued (it must not move in between)
+  void* stage = nullptr;
+  ACCG_HIP(ctx_stage(c, std::max(results_stage_bytes(pairs), 3 * blob + ((size_t)1 << 20)), &stage));
+  accg_phmm_batch* b = nullptr;
+  static const bool trace = getenv("ACCG_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  int st = accg_phmm_batch_create(c, n_regions, reads_ser, reads_bytes, haps_ser, haps_bytes, &b);
+  if (st != ACCG_OK) return st;
+  const auto t1 = std::chrono::steady_clock::now();
+  b->graph_off = true;
+  st = accg_phmm_batch_run(b, mode);
+  const auto t2 = std::chrono::steady_clock::now();
+  if (st == ACCG_OK) st = results_enqueue(b, r->threaded);
+  if (st != ACCG_OK) { accg_phmm_batch_destroy(b); return st; }
+  if (trace) {
+    auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+    static const auto epoch = std::chrono::steady_clock::now();
+    fprintf(stderr, "ring slot %zu: at %.0f us: create %.0f us, run (enqueue) %.0f us, results (enqueue) %.0f us\n", slot, us(epoch, t0), us(t0, t1), us(t1, t2), us(t2, std::chrono::steady_clock::now()));
+  }
+  r->batch[slot] = b;
   return ACCG_OK;
 }
 
@@ -1396,10 +1545,7 @@ extern "C" int accg_phmm_ring_submit_many(accg_phmm_ring* r, int n_regions, cons
                                           const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t* ticket) {
   if (!r || !ticket || n_regions < 1 || !reads_ser || !reads_bytes || !haps_ser || !haps_bytes) return ACCG_ERR_BAD_ARG;
   const size_t slot = (size_t)(r->next_ticket % r->ctx.size());
-  if (r->batch[slot]) return ACCG_ERR_BAD_ARG;                 // the slot's previous ticket has not been waited for
-  accg_ctx* c = r->ctx[slot];
-  ACCG_HIP(hipSetDevice(c->device));
-  // pinned staging large enough for the upload AND the downloads, before anything is queued (it must not move in between)
+  if (r->batch[slot] || (r->threaded && r->slot[slot]->busy)) return ACCG_ERR_BAD_ARG;    // the slot's previous ticket has not been waited for
   uint64_t pairs = 0; size_t blob = 0;
   for (int i = 0; i < n_regions; i++) {
     if (reads_bytes[i] < 4 || haps_bytes[i] < 4 || !reads_ser[i] || !haps_ser[i]) return ACCG_ERR_BAD_WIRE;
@@ -1408,16 +1554,21 @@ extern "C" int accg_phmm_ring_submit_many(accg_phmm_ring* r, int n_regions, cons
     if (nr < 0 || nh < 0) return ACCG_ERR_BAD_WIRE;
     pairs += (uint64_t)nr * (uint64_t)nh; blob += reads_bytes[i] + haps_bytes[i];
   }
-  void* stage = nullptr;
-  ACCG_HIP(ctx_stage(c, std::max(results_stage_bytes(pairs), 3 * blob + ((size_t)1 << 20)), &stage));
-  accg_phmm_batch* b = nullptr;
-  int st = accg_phmm_batch_create(c, n_regions, reads_ser, reads_bytes, haps_ser, haps_bytes, &b);
-  if (st != ACCG_OK) return st;
-  b->graph_off = true;
-  st = accg_phmm_batch_run(b, mode);
-  if (st == ACCG_OK) st = results_enqueue(b);
-  if (st != ACCG_OK) { accg_phmm_batch_destroy(b); return st; }
-  r->batch[slot] = b;
+  if (!r->threaded) {
+    const int st = ring_submit_body(r, slot, n_regions, reads_ser, reads_bytes, haps_ser, haps_bytes, mode, pairs, blob);
+    if (st != ACCG_OK) return st;
+  } else {
+    RingSlot& S = *r->slot[slot];
+    {
+      std::lock_guard<std::mutex> lk(S.mu);
+      S.rs.assign(reads_ser, reads_ser + n_regions); S.hs.assign(haps_ser, haps_ser + n_regions);
+      S.rb.assign(reads_bytes, reads_bytes + n_regions); S.hb.assign(haps_bytes, haps_bytes + n_regions);
+      S.n_regions = n_regions; S.mode = mode; S.pairs = pairs; S.blob = blob;
+      S.status = ACCG_OK; S.err.clear(); S.done = false; S.has_work = true;
+    }
+    S.busy = true;
+    S.cv.notify_all();
+  }
   *ticket = r->next_ticket++;
   return ACCG_OK;
 }
@@ -1431,6 +1582,20 @@ extern "C" int accg_phmm_ring_submit(accg_phmm_ring* r, const void* reads_ser, s
 extern "C" int accg_phmm_ring_wait(accg_phmm_ring* r, uint64_t ticket, float* out_raw, double* out_log10, accg_counters* cnt) {
   if (!r || ticket >= r->next_ticket || ticket + r->ctx.size() < r->next_ticket) return ACCG_ERR_BAD_ARG;
   const size_t slot = (size_t)(ticket % r->ctx.size());
+  if (r->threaded) {
+    RingSlot& S = *r->slot[slot];
+    if (!S.busy) return ACCG_ERR_BAD_ARG;                     // waited for already
+    {
+      std::unique_lock<std::mutex> lk(S.mu);
+      S.cv.wait(lk, [&] { return S.done; });
+    }
+    S.busy = false;
+    if (S.status != ACCG_OK) { set_error_text(S.err.c_str()); return S.status; }
+    if (out_raw && !S.raw.empty()) memcpy(out_raw, S.raw.data(), S.raw.size() * sizeof(float));
+    if (out_log10 && !S.l10.empty()) memcpy(out_log10, S.l10.data(), S.l10.size() * sizeof(double));
+    if (cnt) *cnt = S.cnt;
+    return ACCG_OK;
+  }
   accg_phmm_batch* b = r->batch[slot];
   if (!b) return ACCG_ERR_BAD_ARG;                            // waited for already
   ACCG_HIP(hipSetDevice(b->ctx->device));
@@ -1442,6 +1607,13 @@ extern "C" int accg_phmm_ring_wait(accg_phmm_ring* r, uint64_t ticket, float* ou
 
 extern "C" void accg_phmm_ring_destroy(accg_phmm_ring* r) {
   if (!r) return;
+  for (auto& sp : r->slot) {
+    RingSlot& S = *sp;
+    if (S.busy) { std::unique_lock<std::mutex> lk(S.mu); S.cv.wait(lk, [&] { return S.done; }); }     // a ticket nobody waited for
+    { std::lock_guard<std::mutex> lk(S.mu); S.quit = true; }
+    S.cv.notify_all();
+    if (S.th.joinable()) S.th.join();
+  }
   for (accg_phmm_batch* b : r->batch) if (b) accg_phmm_batch_destroy(b);
   for (accg_ctx* c : r->ctx) accg_shutdown(c);
   delete r;

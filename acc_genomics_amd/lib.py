@@ -48,6 +48,7 @@ def load():
     L.accg_phmm_region.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_region_f64.argtypes = [vp, vp, sz, vp, sz, vp]
     L.accg_phmm_ring_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.accg_phmm_ring_create_threaded.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.accg_phmm_ring_submit.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.POINTER(C.c_uint64)]
     L.accg_phmm_ring_submit_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.c_int, C.POINTER(C.c_uint64)]
     L.accg_phmm_ring_wait.argtypes = [vp, C.c_uint64, vp, vp, C.POINTER(Counters)]
@@ -180,16 +181,21 @@ Context.phmm_region_f64 = _phmm_region_f64
 
 
 class PhmmRing:
-    """Regions in flight (accg_phmm_ring_*): submit() returns a ticket at once, wait(ticket, n_pairs) the region's results."""
+    """Regions in flight (accg_phmm_ring_*): submit() returns a ticket at once, wait(ticket, n_pairs) the region's results.
+    threaded=True (accg_phmm_ring_create_threaded): the host half of a ticket runs on a worker thread of its slot; the blobs are kept
+    alive here until the ticket has been waited for."""
 
-    def __init__(self, ctx, slots=4):
-        self.ctx, self.L, self.slots = ctx, ctx.L, slots
+    def __init__(self, ctx, slots=4, threaded=False):
+        self.ctx, self.L, self.slots, self.threaded = ctx, ctx.L, slots, threaded
         self.h = C.c_void_p()
-        _check(self.L.accg_phmm_ring_create(ctx.h, slots, C.byref(self.h)))
+        self._keep = {}
+        _check((self.L.accg_phmm_ring_create_threaded if threaded else self.L.accg_phmm_ring_create)(ctx.h, slots, C.byref(self.h)))
 
     def submit(self, reads_ser, haps_ser, mode=ACCG_PHMM_FAST):
         t = C.c_uint64()
         _check(self.L.accg_phmm_ring_submit(self.h, reads_ser, len(reads_ser), haps_ser, len(haps_ser), mode, C.byref(t)))
+        if self.threaded:
+            self._keep[t.value] = (reads_ser, haps_ser)
         return t.value
 
     def submit_many(self, regions, mode=ACCG_PHMM_FAST):
@@ -202,19 +208,25 @@ class PhmmRing:
         hb = (C.c_size_t * n)(*[len(h) for _, h in keep])
         t = C.c_uint64()
         _check(self.L.accg_phmm_ring_submit_many(self.h, n, rs, rb, hs, hb, mode, C.byref(t)))
+        if self.threaded:
+            self._keep[t.value] = keep
         return t.value
 
     def wait(self, ticket, n_pairs, want_log10=True):
         raw = np.zeros(n_pairs, np.float32)
         l10 = np.zeros(n_pairs, np.float64) if want_log10 else None
         cnt = Counters()
-        _check(self.L.accg_phmm_ring_wait(self.h, ticket, raw.ctypes.data, l10.ctypes.data if want_log10 else None, C.byref(cnt)))
+        try:
+            _check(self.L.accg_phmm_ring_wait(self.h, ticket, raw.ctypes.data, l10.ctypes.data if want_log10 else None, C.byref(cnt)))
+        finally:
+            self._keep.pop(ticket, None)
         return raw, l10, cnt
 
     def close(self):
         if self.h:
-            self.L.accg_phmm_ring_destroy(self.h)
+            self.L.accg_phmm_ring_destroy(self.h)       # (joins the workers: only then may the blobs go)
             self.h = C.c_void_p()
+            self._keep.clear()
 
     def __enter__(self):
         return self

@@ -579,6 +579,29 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
             t_stream = med(stream)
         out["c3_stream"] = {"regions": n_st, "regions_per_ticket": G, "tickets_in_flight": 3, "ms_total": t_stream * 1e3, "value": st_cells / t_stream / 1e9,
                             "unit": "GCUPS", "what": "accg_phmm_ring_submit_many / _wait over the first %d configs[3] regions, one caller thread, median of 3 passes" % n_st}
+        # a stream twice as long through a threaded ring: the host half of every ticket (and the end of its device half: download, log10)
+        # on the worker thread of its slot, eight tickets in flight
+        n_th, S_th = 8 * n_c3, 8
+        regs3 = regs2 + [c3_region(k) for k in range(n_st, n_th)]
+        ser3 = ser2 + [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs3[n_st:]]
+        th_cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs3)
+
+        def stream_thr():
+            pend = []
+            for g0 in range(0, n_th, G):
+                if len(pend) == S_th:
+                    t, mm = pend.pop(0)
+                    rg8.wait(t, mm)
+                pend.append((rg8.submit_many([(a, b) for a, b, _ in ser3[g0:g0 + G]], mode), sum(m for _, _, m in ser3[g0:g0 + G])))
+            for t, mm in pend:
+                rg8.wait(t, mm)
+
+        with A.PhmmRing(ctx, S_th, threaded=True) as rg8:
+            stream_thr()                      # (once more than the others before timing: eight slots' device blocks and staging to warm)
+            t_thr = med(stream_thr)
+        out["c3_stream_threaded"] = {"regions": n_th, "regions_per_ticket": G, "tickets_in_flight": S_th, "ms_total": t_thr * 1e3, "value": th_cells / t_thr / 1e9,
+                                     "unit": "GCUPS", "what": "accg_phmm_ring_create_threaded: %d configs[3] regions, the host half of every ticket and its download + "
+                                                              "log10 on the worker thread of its slot, one caller thread, median of 3 passes" % n_th}
     out["note"] = "host memory to host memory, parse + job sizing + upload + kernels + download + log10 all inside; not the headline value"
     return out
 

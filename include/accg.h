@@ -92,6 +92,11 @@ int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, c
  * results, bit for bit, as accg_phmm_region.  The blobs may be reused as soon as submit returns.  One thread at a time per ring. */
 typedef struct accg_phmm_ring accg_phmm_ring;
 int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out);
+/* The same ring with a worker thread per slot: submit only checks the blobs' headers, hands them to the slot's worker and returns, so
+ * the host halves of up to `slots` tickets run side by side (each on its share of the host threads).  THE BLOBS (and nothing else: the
+ * pointer and size arrays are copied) MUST STAY UNTOUCHED UNTIL THE TICKET HAS BEEN WAITED FOR; errors of the host half come back from
+ * accg_phmm_ring_wait.  Still one caller thread at a time per ring. */
+int accg_phmm_ring_create_threaded(accg_ctx* ctx, int slots, accg_phmm_ring** out);
 int accg_phmm_ring_submit(accg_phmm_ring* ring, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
                           int mode, uint64_t* ticket);
 /* several regions under one ticket (one device batch: its results come back concatenated in region order, like accg_phmm_batch_results) */

@@ -456,6 +456,45 @@ def test_ring_equals_one_shot(ctx):
                 ring.wait(ts[0], ser[0][2])
 
 
+def test_threaded_ring_equals_one_shot(ctx):
+    """accg_phmm_ring_create_threaded: the host half of every ticket on a worker thread of its slot.  Same bits as the blocking call,
+    single regions and several under one ticket, with every slot busy; a malformed blob whose header passes the submit-time check
+    comes back as an error from wait, and the ring stays usable."""
+    rng = synth.rng_for(360)
+    regs = [synth.make_region(rng, int(rng.integers(1, 40)), int(rng.integers(1, 9)), (10, 200), (20, 400), n_frac=0.01, unrelated_frac=0.25)
+            for _ in range(17)]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
+    want = [ctx.phmm_region(a, b, n) for a, b, n in ser]
+    for slots in (1, 4):
+        with A.PhmmRing(ctx, slots, threaded=True) as ring:
+            got, pend = [], []
+            for a, b, n in ser:
+                if len(pend) == slots:
+                    t, m = pend.pop(0)
+                    got.append(ring.wait(t, m))
+                pend.append((ring.submit(a, b), n))
+            while pend:
+                t, m = pend.pop(0)
+                got.append(ring.wait(t, m))
+            for (wr, wl, wc), (gr, gl, gc) in zip(want, got):
+                assert wr.tobytes() == gr.tobytes() and wl.tobytes() == gl.tobytes() and wc.rescued == gc.rescued
+            ts = [(ring.submit_many([(a, b) for a, b, _ in ser[k::slots]]), sum(n for _, _, n in ser[k::slots]), k) for k in range(slots)]
+            with pytest.raises(A.AccgError):
+                ring.submit(ser[0][0], ser[0][1])           # every slot is busy
+            for t, m, k in ts:
+                gr, gl, _ = ring.wait(t, m)
+                assert gr.tobytes() == b"".join(w[0].tobytes() for w in want[k::slots])
+                assert gl.tobytes() == b"".join(w[1].tobytes() for w in want[k::slots])
+            bad = bytearray(ser[3][0])
+            bad[-1:] = b""                                   # truncated reads blob: the header is fine, the parse fails on the worker
+            t = ring.submit(bytes(bad), ser[3][1])
+            with pytest.raises(A.AccgError):
+                ring.wait(t, ser[3][2])
+            t = ring.submit(ser[3][0], ser[3][1])
+            gr, _, _ = ring.wait(t, ser[3][2])
+            assert gr.tobytes() == want[3][0].tobytes()
+
+
 def test_time_in_step_and_clock(ctx):
     """The bench's instruments: the sweep timed inside whole passes (events on its launch stream) is shorter than the pass, and the
     clock the sweep kernel measures on itself is a plausible shader clock."""
