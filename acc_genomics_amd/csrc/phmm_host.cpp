@@ -758,26 +758,22 @@ void partition(accg_phmm_batch& b) {
     order[i] = {~key, (uint32_t)i};
   }
   std::sort(order.begin(), order.end());
-  {
-    std::vector<Job> sorted;
-    sorted.reserve(jobs.size());
-    for (const auto& kv : order) sorted.push_back(jobs[kv.second]);
-    jobs.swap(sorted);
-  }
+  // (the jobs are read through the sorted index: copying them into order first cost as much as the sort)
   b.work.clear();
   b.work.reserve(jobs.size() * 2);
   for (size_t i = 0; i < jobs.size(); i++) {
-    if (b.launches.empty() || b.launches.back().K != jobs[i].K || b.launches.back().lpp != jobs[i].lpp || b.launches.back().form != jobs[i].form ||
-        b.launches.back().striped != jobs[i].striped || b.launches.back().wg != jobs[i].wg)
-      b.launches.push_back({jobs[i].K, jobs[i].lpp, jobs[i].form, jobs[i].striped, jobs[i].wg, (uint32_t)b.work.size(), 0, 0, 0, 0, 0});
+    const Job& J = jobs[order[i].second];
+    if (b.launches.empty() || b.launches.back().K != J.K || b.launches.back().lpp != J.lpp || b.launches.back().form != J.form ||
+        b.launches.back().striped != J.striped || b.launches.back().wg != J.wg)
+      b.launches.push_back({J.K, J.lpp, J.form, J.striped, J.wg, (uint32_t)b.work.size(), 0, 0, 0, 0, 0});
     KLaunch& L = b.launches.back();
-    b.work.push_back(jobs[i].w);
-    if (jobs[i].wg == 2) b.work.push_back(jobs[i].w2);
-    L.n_work += (uint32_t)jobs[i].wg;
-    L.cost += jobs[i].cost * (uint64_t)jobs[i].wg;
-    b.any_form5 |= jobs[i].form == 5 && !jobs[i].striped && jobs[i].lpp * jobs[i].K > 16;
-    L.stream_cap = std::max(L.stream_cap, (int)((jobs[i].stream_len + 63) / 64 * 64));
-    L.haps_cap = std::max(L.haps_cap, (int)std::max(jobs[i].w.n_haps, jobs[i].wg == 2 ? jobs[i].w2.n_haps : 0u));
+    b.work.push_back(J.w);
+    if (J.wg == 2) b.work.push_back(J.w2);
+    L.n_work += (uint32_t)J.wg;
+    L.cost += J.cost * (uint64_t)J.wg;
+    b.any_form5 |= J.form == 5 && !J.striped && J.lpp * J.K > 16;
+    L.stream_cap = std::max(L.stream_cap, (int)((J.stream_len + 63) / 64 * 64));
+    L.haps_cap = std::max(L.haps_cap, (int)std::max(J.w.n_haps, J.wg == 2 ? J.w2.n_haps : 0u));
   }
   // The fast mode's list: consecutive classes of one merge class become one launch -- when the batch is small.  configs[3] shards,
   // whole pass, separate launches -> one launch: 64 regions 1.06 -> 0.92 ms, 128 regions 1.75 -> 1.59, 256 regions 3.21 -> 2.92,
