@@ -72,6 +72,10 @@ struct accg_ctx {
   static constexpr int N_AUX = 4;
   hipStream_t aux[N_AUX] = {};
   hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {};
+  // The tail of a PairHMM pass (rescue planner, fp64 rescue, strict re-runs) runs on a stream of its own with its own forked streams,
+  // so that the next pass's sweep can start behind this pass's sweep instead of behind its tail (phmm_host.cpp: run_direct).
+  hipStream_t tail = nullptr, aux_t[N_AUX] = {};
+  hipEvent_t ev_fork_t = nullptr, ev_join_t[N_AUX] = {};
 };
 
 namespace accg {
@@ -85,6 +89,8 @@ struct SyncOnError {
 };
 // aux streams wait for everything queued on ctx->stream so far / ctx->stream waits for everything queued on the aux streams
 hipError_t ctx_fork(accg_ctx* c);
+hipError_t ctx_fork_tail(accg_ctx* c);       // the same for the tail stream and its forked streams
+hipError_t ctx_join_tail(accg_ctx* c);
 hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p);   // pinned staging of at least `bytes`
 hipError_t ctx_join(accg_ctx* c);
 }  // namespace accg

@@ -177,6 +177,7 @@ extern "C" int accg_ctx_synchronize(accg_ctx* ctx) {
   if (!ctx) return ACCG_ERR_NOT_INITIALISED;
   ACCG_HIP(hipSetDevice(ctx->device));
   ACCG_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->tail) ACCG_HIP(hipStreamSynchronize(ctx->tail));     // the tails of PairHMM passes (queued behind their sweeps)
   return ACCG_OK;
 }
 

@@ -76,6 +76,12 @@ extern "C" int accg_init(int device, accg_ctx** out) {
     ACCG_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
   }
   ACCG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  ACCG_HIP(hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
+  for (int i = 0; i < accg_ctx::N_AUX; i++) {
+    ACCG_HIP(hipStreamCreateWithFlags(&c->aux_t[i], hipStreamNonBlocking));
+    ACCG_HIP(hipEventCreateWithFlags(&c->ev_join_t[i], hipEventDisableTiming));
+  }
+  ACCG_HIP(hipEventCreateWithFlags(&c->ev_fork_t, hipEventDisableTiming));
   const HostTables& t = host_tables();
   const size_t nf = 128 * 3 + 8256, bytes = nf * sizeof(float) + nf * sizeof(double);
   ACCG_HIP(hipMalloc(&c->tab_mem, bytes));
@@ -104,6 +110,12 @@ extern "C" void accg_shutdown(accg_ctx* c) {
     if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < accg_ctx::N_AUX; i++) {
+    if (c->aux_t[i]) { hipStreamSynchronize(c->aux_t[i]); hipStreamDestroy(c->aux_t[i]); }
+    if (c->ev_join_t[i]) hipEventDestroy(c->ev_join_t[i]);
+  }
+  if (c->tail) { hipStreamSynchronize(c->tail); hipStreamDestroy(c->tail); }
+  if (c->ev_fork_t) hipEventDestroy(c->ev_fork_t);
   c->pool.drain();
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->tab_mem) hipFree(c->tab_mem);
@@ -203,6 +215,19 @@ hipError_t ctx_join(accg_ctx* c) {
   }
   return e;
 }
+hipError_t ctx_fork_tail(accg_ctx* c) {
+  hipError_t e = hipEventRecord(c->ev_fork_t, c->tail);
+  for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) e = hipStreamWaitEvent(c->aux_t[i], c->ev_fork_t, 0);
+  return e;
+}
+hipError_t ctx_join_tail(accg_ctx* c) {
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) {
+    e = hipEventRecord(c->ev_join_t[i], c->aux_t[i]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->tail, c->ev_join_t[i], 0);
+  }
+  return e;
+}
 }  // namespace accg
 extern "C" void* accg_stream(accg_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int accg_device_name(accg_ctx* c, char* buf, size_t n) {
@@ -295,7 +320,19 @@ struct accg_phmm_batch {
   bool has_n = false;          // some haplotype contains an 'N': the dist table needs its fifth slab
   int force_wpc = 0;           // ACCG_PHMM_WPC: > 0 pins every launch to that many wavefronts per CU, < 0 pins nothing
   DevBuf<uint8_t> d_arena;       // one allocation behind every buffer below
-  size_t res_off = 0;            // arena offset of the results block [n_rescued u64][out f32 x (pairs+1)]
+  uint8_t* res_ptr = nullptr;    // the results block [n_rescued u64][out f32 x (pairs+1)] of the pass buffers in use
+  // Pass buffers (d_out, d_out64, d_state, d_rescue_jobs, d_redo, d_flagged, res_ptr): everything a pass writes.  A batch that is run
+  // again gets a SECOND set (d_alt, allocated at its second run) and alternates between the two, so that a pass's sweep can start
+  // while the tail of the pass before -- planner, fp64 rescue, re-runs, on the context's tail stream -- is still at work on the
+  // other set (run_direct).  `alt` holds the set not in use; tail_done of a set = its last tail has been queued up to there.
+  struct PassSet { float* out = nullptr; double* out64 = nullptr; uint32_t *state = nullptr, *redo = nullptr, *flagged = nullptr; PhmmWork* jobs = nullptr;
+                   uint8_t* res = nullptr; hipEvent_t tail_done = nullptr; bool tail_pending = false; };
+  PassSet alt;
+  hipEvent_t tail_done = nullptr, ev_sweep = nullptr;
+  bool tail_pending = false;     // the set in use: a tail has been queued on the tail stream and not yet been joined into the main stream
+  DevBuf<uint8_t> d_alt;
+  size_t pass_bytes = 0, off_alt_out64 = 0, off_alt_state = 0, off_alt_out = 0, off_alt_jobs = 0, off_alt_redo = 0, off_alt_flagged = 0, alt_clear_bytes = 0;
+  uint64_t runs = 0;
   DevBuf<uint8_t> d_rblob, d_hblob;
   DevBuf<SeqRef> d_rd, d_hp;
   DevBuf<uint32_t> d_rd_out, d_hp_local;
@@ -904,8 +941,10 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
   if (ev_end) ACCG_HIP(hipEventRecord(ev_end, b->ctx->stream));
   return ACCG_OK;
 }
-int launch_rescue(accg_phmm_batch* b, int mode) {
-  hipStream_t s = b->ctx->stream;
+// on_tail: on the context's tail stream and its forked streams (a pipelined pass, run_direct) instead of the main stream's
+int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
+  hipStream_t s = on_tail ? b->ctx->tail : b->ctx->stream;
+  hipStream_t* const aux = on_tail ? b->ctx->aux_t : b->ctx->aux;
   PhmmPlanArgs p;
   p.regions = b->d_regions.p; p.chunks = b->d_chunks.p; p.sorted_reads = b->d_sorted_reads.p; p.rd = b->d_rd.p;
   p.rd_out = b->d_rd_out.p; p.read_flag = b->d_state.p; p.jobs = b->d_rescue_jobs.p; p.counts = b->d_state.p + state_counts(*b);
@@ -942,14 +981,14 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
   }
   n_launch += (win_units[0] != 0) + (win_units[1] != 0);
   const bool fork = n_launch > 1;
-  if (fork) ACCG_HIP(ctx_fork(b->ctx));
+  if (fork) ACCG_HIP(on_tail ? ctx_fork_tail(b->ctx) : ctx_fork(b->ctx));
   int rr = 0;
   PhmmRescueSet rs;
   for (int c = 0; c <= PHMM_RESCUE_CLASSES; c++) rs.off[c] = b->rescue_off[c];
   rs.counts = b->d_state.p + state_counts(*b);
   for (int w = 0; w < 2; w++) {
     if (!win_units[w]) continue;
-    hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
+    hipStream_t st = fork ? aux[rr++ % accg_ctx::N_AUX] : s;
     a.job_count = nullptr; a.job_map = nullptr; a.is_redo = 0;
     a.redo_count = b->d_state.p + state_redo(*b);          // one list for all merged classes: the first class's counter, the list from slot 0
     a.redo_list = b->d_redo.p;
@@ -959,7 +998,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
     const uint32_t bound = (uint32_t)b->rescue_bound[c];       // < 2^32: checked at batch creation
     if (!bound || (merged && phmm_rescue_window(c) >= 0)) continue;
     a.job_count = b->d_state.p + state_counts(*b) + c;
-    hipStream_t st = fork ? b->ctx->aux[rr++ % accg_ctx::N_AUX] : s;
+    hipStream_t st = fork ? aux[rr++ % accg_ctx::N_AUX] : s;
     int lpp_c, k_c;
     phmm_rescue_shape(c, &lpp_c, &k_c);
     const bool strict = mode == ACCG_PHMM_STRICT;
@@ -974,7 +1013,7 @@ int launch_rescue(accg_phmm_batch* b, int mode) {
       ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, true, phmm_rescue_striped(c), r, b->rescue_off[c], bound, st, PHMM_REDO_GRID));
     }
   }
-  if (fork) ACCG_HIP(ctx_join(b->ctx));
+  if (fork) ACCG_HIP(on_tail ? ctx_join_tail(b->ctx) : ctx_join(b->ctx));
   if (win_units[0] || win_units[1]) {     // behind both windows: the items they listed, in the reference's operation order
     PhmmArgs<double> r = a;
     r.job_count = nullptr; r.job_map = nullptr; r.is_redo = 1;
@@ -1092,8 +1131,20 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_out64.place(base, o_out64, b->pairs + 1);
   b->d_state.place(base, o_state, sw);
   b->d_out.place(base, o_out, b->pairs + 1);
-  b->res_off = o_out - sizeof(unsigned long long);
-  if (state_nresc(*b) * sizeof(uint32_t) + o_state != b->res_off) return ACCG_ERR_BAD_ARG;   // layout invariant of the single D2H
+  b->res_ptr = base + (o_out - sizeof(unsigned long long));
+  if (state_nresc(*b) * sizeof(uint32_t) + o_state != o_out - sizeof(unsigned long long)) return ACCG_ERR_BAD_ARG;   // layout invariant of the single D2H
+  {   // the layout of a second set of pass buffers (allocated if the batch is run a second time): [flagged][jobs][redo][out64][state | out]
+    size_t o2 = 0;
+    auto take2 = [&](size_t bytes) { o2 = (o2 + 255) / 256 * 256; const size_t o = o2; o2 += bytes; return o; };
+    b->off_alt_flagged = take2((b->rd.size() + 1) * sizeof(uint32_t));
+    b->off_alt_jobs = take2(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(PhmmWork));
+    b->off_alt_redo = take2(((size_t)b->rescue_off[PHMM_RESCUE_CLASSES] + 1) * sizeof(uint32_t));
+    b->off_alt_out64 = take2((b->pairs + 1) * sizeof(double));
+    b->off_alt_state = take2((sw + (sw & 1)) * sizeof(uint32_t) + (b->pairs + 1) * sizeof(float));
+    b->off_alt_out = b->off_alt_state + (sw + (sw & 1)) * sizeof(uint32_t);
+    b->alt_clear_bytes = o2 - b->off_alt_out64;          // out64, state, out: zero before the first use, like the first set
+    b->pass_bytes = o2 + 256;
+  }
   void* stage_v = nullptr;
   ACCG_HIP(ctx_stage(ctx, upload_bytes + 16, &stage_v));
   const auto tq2 = std::chrono::steady_clock::now();
@@ -1140,10 +1191,68 @@ extern "C" uint64_t accg_phmm_batch_algorithmic_bytes(const accg_phmm_batch* b) 
 extern "C" uint64_t accg_phmm_batch_jobs(const accg_phmm_batch* b) { return b ? b->work.size() : 0; }
 
 namespace {
-int run_direct(accg_phmm_batch* b, int mode) {
-  int st = launch_f32(b, mode);
+bool graphs_wanted();
+// Passes of one batch CAN be pipelined (ACCG_PHMM_PIPELINE=1; off by default): a pass's tail (planner, fp64 rescue, re-runs) goes
+// onto the context's tail stream behind its sweep, and the NEXT pass's sweep starts behind this pass's sweep, on the other set of
+// pass buffers; whoever needs a pass's results joins the tail first (join_tail).  Measured (tools/ab_step.py): configs[3] 10.89 ->
+// 10.75 ms per pass, a 128-region shard 1.547 -> 1.523 -- and configs[1] 0.273 -> 0.321 ms: its sweep pins the CUs' LDS (eight
+// workgroups of 20 KB), so the tail's workgroups (22 KB each, empty as they are) cannot start before the next sweep's workgroups
+// retire, and the tail of pass i ends up holding back the sweep of pass i + 2.  Not worth 1.5 %: off.
+bool pipeline_on() {
+  static const bool on = [] { const char* e = getenv("ACCG_PHMM_PIPELINE"); return e && e[0] == '1'; }();
+  return on && !graphs_wanted();
+}
+void swap_sets(accg_phmm_batch* b) {
+  accg_phmm_batch::PassSet cur;
+  cur.out = b->d_out.p; cur.out64 = b->d_out64.p; cur.state = b->d_state.p; cur.redo = b->d_redo.p; cur.flagged = b->d_flagged.p;
+  cur.jobs = b->d_rescue_jobs.p; cur.res = b->res_ptr; cur.tail_done = b->tail_done; cur.tail_pending = b->tail_pending;
+  b->d_out.p = b->alt.out; b->d_out64.p = b->alt.out64; b->d_state.p = b->alt.state; b->d_redo.p = b->alt.redo; b->d_flagged.p = b->alt.flagged;
+  b->d_rescue_jobs.p = b->alt.jobs; b->res_ptr = b->alt.res; b->tail_done = b->alt.tail_done; b->tail_pending = b->alt.tail_pending;
+  b->alt = cur;
+}
+int ensure_alt(accg_phmm_batch* b) {          // the second set of pass buffers, at the batch's second run
+  if (b->d_alt.p) return ACCG_OK;
+  PoolScope pool_scope(&b->ctx->pool);
+  int st = b->d_alt.alloc(b->pass_bytes);
   if (st != ACCG_OK) return st;
-  return launch_rescue(b, mode);
+  uint8_t* base = b->d_alt.p;
+  ACCG_HIP(hipMemsetAsync(base + b->off_alt_out64, 0, b->alt_clear_bytes, b->ctx->stream));
+  b->alt.out = (float*)(base + b->off_alt_out); b->alt.out64 = (double*)(base + b->off_alt_out64); b->alt.state = (uint32_t*)(base + b->off_alt_state);
+  b->alt.redo = (uint32_t*)(base + b->off_alt_redo); b->alt.flagged = (uint32_t*)(base + b->off_alt_flagged); b->alt.jobs = (PhmmWork*)(base + b->off_alt_jobs);
+  b->alt.res = base + b->off_alt_out - sizeof(unsigned long long);
+  b->alt.tail_pending = false;
+  ACCG_HIP(hipEventCreateWithFlags(&b->alt.tail_done, hipEventDisableTiming));
+  return ACCG_OK;
+}
+// the main stream waits for every tail queued so far (the tail stream is in order: both sets' last tails)
+int join_tail(accg_phmm_batch* b) {
+  if (b->alt.tail_pending) { ACCG_HIP(hipStreamWaitEvent(b->ctx->stream, b->alt.tail_done, 0)); b->alt.tail_pending = false; }
+  if (b->tail_pending) { ACCG_HIP(hipStreamWaitEvent(b->ctx->stream, b->tail_done, 0)); b->tail_pending = false; }
+  return ACCG_OK;
+}
+int run_direct(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
+  int st;
+  if (!pipeline_on()) {
+    if ((st = launch_f32(b, mode, ev_begin, ev_end)) != ACCG_OK) return st;
+    return launch_rescue(b, mode);
+  }
+  accg_ctx* c = b->ctx;
+  if (b->runs >= 1) {
+    if ((st = ensure_alt(b)) != ACCG_OK) return st;
+    swap_sets(b);
+  }
+  b->runs++;
+  if (!b->ev_sweep) ACCG_HIP(hipEventCreateWithFlags(&b->ev_sweep, hipEventDisableTiming));
+  if (!b->tail_done) ACCG_HIP(hipEventCreateWithFlags(&b->tail_done, hipEventDisableTiming));
+  // this set's previous pass (two passes ago): its tail read the flags and results this sweep is about to overwrite
+  if (b->tail_pending) { ACCG_HIP(hipStreamWaitEvent(c->stream, b->tail_done, 0)); b->tail_pending = false; }
+  if ((st = launch_f32(b, mode, ev_begin, ev_end)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(b->ev_sweep, c->stream));
+  ACCG_HIP(hipStreamWaitEvent(c->tail, b->ev_sweep, 0));
+  if ((st = launch_rescue(b, mode, true)) != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(b->tail_done, c->tail));
+  b->tail_pending = true;
+  return ACCG_OK;
 }
 bool graphs_wanted() {
   // Off unless ACCG_PHMM_GRAPH=1.  Measured on MI355X (tools/ab_step.py, round 3): the replayed graph is SLOWER than the plain
@@ -1159,7 +1268,7 @@ int run_graph(accg_phmm_batch* b, int mode) {
   hipStream_t s = b->ctx->stream;
   if (!b->graph_exec[gi]) {
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); b->graph_off = true; return run_direct(b, mode); }
-    const int st = run_direct(b, mode);
+    const int st = run_direct(b, mode);       // (pipeline_on() is false when graphs are wanted: one stream, one set)
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s, &g);
     if (st != ACCG_OK || e != hipSuccess || !g) {
@@ -1189,6 +1298,7 @@ extern "C" int accg_phmm_batch_run(accg_phmm_batch* b, int mode) {
 extern "C" int accg_phmm_batch_run_f64(accg_phmm_batch* b) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
+  { const int stj = join_tail(b); if (stj != ACCG_OK) return stj; }
   PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, b->ctx->tab_d);
   for (const KLaunch& l : b->launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
@@ -1210,13 +1320,16 @@ extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int
   ACCG_HIP(hipSetDevice(b->ctx->device));
   accg_ctx* c = b->ctx;
   int st;
+  if ((st = join_tail(b)) != ACCG_OK) return st;
   for (int i = 0; i < warmup; i++) {
     if ((st = what == 0 ? run_pass(b, mode) : launch_f32(b, mode)) != ACCG_OK) return st;
   }
+  if ((st = join_tail(b)) != ACCG_OK) return st;
   ACCG_HIP(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < iters; i++) {
     if ((st = what == 0 ? run_pass(b, mode) : launch_f32(b, mode)) != ACCG_OK) return st;
   }
+  if ((st = join_tail(b)) != ACCG_OK) return st;          // the last passes' tails belong to the time
   ACCG_HIP(hipEventRecord(c->ev1, c->stream));
   ACCG_HIP(hipEventSynchronize(c->ev1));
   float ms = 0;
@@ -1238,11 +1351,12 @@ extern "C" int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int it
   struct Drop { std::vector<hipEvent_t>& e; ~Drop() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); } } drop{ev};
   for (hipEvent_t& e : ev) ACCG_HIP(hipEventCreate(&e));
   int st;
+  if ((st = join_tail(b)) != ACCG_OK) return st;
   ACCG_HIP(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < iters; i++) {
-    if ((st = launch_f32(b, mode, ev[2 * i], ev[2 * i + 1])) != ACCG_OK) return st;
-    if ((st = launch_rescue(b, mode)) != ACCG_OK) return st;
+    if ((st = run_direct(b, mode, ev[2 * i], ev[2 * i + 1])) != ACCG_OK) return st;
   }
+  if ((st = join_tail(b)) != ACCG_OK) return st;
   ACCG_HIP(hipEventRecord(c->ev1, c->stream));
   ACCG_HIP(hipEventSynchronize(c->ev1));
   float ms = 0;
@@ -1281,13 +1395,14 @@ size_t results_stage_bytes(uint64_t pairs) { return (sizeof(unsigned long long) 
 // NEXT copy submitted to that queue, another slot's upload, inside hipMemcpyAsync on that slot's worker (measured: creations of
 // 1.7 ms took 7 to 11 ms while the device worked through the tickets ahead).
 int results_enqueue(accg_phmm_batch* b, bool late) {
+  { const int stj = join_tail(b); if (stj != ACCG_OK) return stj; }
   const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
   void* stage_v = nullptr;
   ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));      // (sized by the submitter before the upload: no reallocation here)
   b->results_late = late;
   if (late) return ACCG_OK;
   uint8_t* stage = (uint8_t*)stage_v;
-  ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
+  ACCG_HIP(hipMemcpyAsync(stage, b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
   if (n) ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
   return ACCG_OK;
 }
@@ -1296,7 +1411,7 @@ int results_finish(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_c
   const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
   uint8_t* stage = (uint8_t*)b->ctx->h_stage;
   if (b->results_late) {
-    ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
+    ACCG_HIP(hipMemcpyAsync(stage, b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
     ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   }
   unsigned long long nresc = 0;
@@ -1323,6 +1438,7 @@ int results_finish(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_c
 extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* cnt) {
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
+  { const int stj = join_tail(b); if (stj != ACCG_OK) return stj; }
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   // one copy: [n_rescued][out f32]; a second one for the fp64 values only when something was rescued
   const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float);
@@ -1330,7 +1446,7 @@ extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, doubl
   void* stage_v = nullptr;
   ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));
   uint8_t* stage = (uint8_t*)stage_v;
-  ACCG_HIP(hipMemcpyAsync(stage, b->d_arena.p + b->res_off, head, hipMemcpyDeviceToHost, b->ctx->stream));
+  ACCG_HIP(hipMemcpyAsync(stage, b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
   ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   unsigned long long nresc = 0;
   memcpy(&nresc, stage, sizeof nresc);
@@ -1358,7 +1474,12 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
+  if (b->ctx->tail && (b->tail_pending || b->alt.tail_pending || b->runs)) hipStreamSynchronize(b->ctx->tail);
   for (hipGraphExec_t& g : b->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  if (b->ev_sweep) hipEventDestroy(b->ev_sweep);
+  if (b->tail_done) hipEventDestroy(b->tail_done);
+  if (b->alt.tail_done) hipEventDestroy(b->alt.tail_done);
+  b->d_alt.release();
   b->d_arena.release();
   delete b;
 }
@@ -1391,6 +1512,7 @@ extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t rea
   hipEventRecord(ctx->ev0, ctx->stream);
   b->graph_off = true;            // a single pass: capturing and instantiating a graph would cost more than it saves
   st = accg_phmm_batch_run(b, mode);
+  if (st == ACCG_OK) st = join_tail(b);
   hipEventRecord(ctx->ev1, ctx->stream);
   auto t2 = t1, t3 = t1;
   if (st == ACCG_OK) {
