@@ -1169,10 +1169,14 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const auto tq3 = std::chrono::steady_clock::now();
   if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
   const auto tq4 = std::chrono::steady_clock::now();
-  ACCG_HIP(hipMemsetAsync(base + o_out64, 0, (o_out - o_out64) + (b->pairs + 1) * sizeof(float), s));   // out64, state, out
-  if (b->any_form5 && b->n_rows) {       // the per-row records of the five-operation sweep (phmm_dev.h: PhmmRowRecs), from the uploaded reads
+  // out64, state, out start at zero: cleared by the kernel that writes the per-row records of the five-operation sweep (phmm_dev.h:
+  // PhmmRowRecs, from the uploaded reads) when there is one -- a hipMemsetAsync of a megabyte or two costs the host 100 to 150 us
+  const size_t clear_bytes = (o_out - o_out64) + (b->pairs + 1) * sizeof(float);       // (o_out64 is 256-byte aligned, sizes are multiples of 4)
+  if (b->any_form5 && b->n_rows && clear_bytes / 4 < (1ull << 32)) {
     const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, ctx->tab_f);
-    ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), nullptr, 0, s));
+    ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), reinterpret_cast<uint32_t*>(base + o_out64), (uint32_t)(clear_bytes / 4), s));
+  } else {
+    ACCG_HIP(hipMemsetAsync(base + o_out64, 0, clear_bytes, s));
   }
   if (!ctx->async_create) ACCG_HIP(hipStreamSynchronize(s));   // the staging buffer is reused by the next call
   if (getenv("ACCG_TRACE")) {
