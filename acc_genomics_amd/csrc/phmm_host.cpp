@@ -992,7 +992,8 @@ int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
     a.job_count = nullptr; a.job_map = nullptr; a.is_redo = 0;
     a.redo_count = b->d_state.p + state_redo(*b);          // one list for all merged classes: the first class's counter, the list from slot 0
     a.redo_list = b->d_redo.p;
-    ACCG_HIP(phmm_launch_rescue_multi(w, wg, win_lds[w], a, rs, (uint32_t)std::min<uint64_t>(win_units[w], PHMM_RESCUE_GRID_DEFAULT), st));
+    static const uint64_t grid_cap = [] { const char* e = getenv("ACCG_PHMM_RESCUE_GRID"); return e && atoi(e) > 0 ? (uint64_t)atoi(e) : (uint64_t)PHMM_RESCUE_GRID_DEFAULT; }();
+    ACCG_HIP(phmm_launch_rescue_multi(w, wg, win_lds[w], a, rs, (uint32_t)std::min<uint64_t>(win_units[w], grid_cap), st));
   }
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
     const uint32_t bound = (uint32_t)b->rescue_bound[c];       // < 2^32: checked at batch creation
