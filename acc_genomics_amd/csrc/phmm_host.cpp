@@ -812,15 +812,14 @@ void partition(accg_phmm_batch& b) {
     L.stream_cap = std::max(L.stream_cap, (int)((J.stream_len + 63) / 64 * 64));
     L.haps_cap = std::max(L.haps_cap, (int)std::max(J.w.n_haps, J.wg == 2 ? J.w2.n_haps : 0u));
   }
-  // The fast mode's list: consecutive classes of one merge class become one launch -- when the batch is small.  configs[3] shards,
-  // whole pass, separate launches -> one launch: 64 regions 1.06 -> 0.92 ms, 128 regions 1.75 -> 1.59, 256 regions 3.21 -> 2.92,
-  // 512 regions 5.92 -> 5.73.  At 1024 regions (190 k jobs) the sweep alone is 1.5 % faster merged but the whole pass measured 3 % slower
-  // on two boxes and 2 % faster on a third (one whose clocks are lower throughout), so large batches keep the separate launches: the
-  // rule is "at most 24 rounds of sixteen wavefronts per CU in the whole batch".  ACCG_PHMM_MERGE=0: never, =1: always.
+  // The fast mode's list: consecutive classes of one merge class become one launch.  configs[3] shards, whole pass, separate launches ->
+  // one launch: 64 regions 1.06 -> 0.92 ms, 128 regions 1.75 -> 1.59, 256 regions 3.21 -> 2.92, 512 regions 5.82 -> 5.49, 1024 regions
+  // 11.02 -> 10.82 on one box and 10.99 -> 10.95 on another.  (With the rescue's first layout -- two launches per class on the same
+  // streams -- the 1024-region pass had measured 3 % SLOWER merged on two boxes although the sweep itself was faster; with the merged
+  // rescue windows that is gone.)  ACCG_PHMM_MERGE=0: one launch per class.
   {
     const char* em = getenv("ACCG_PHMM_MERGE");          // read per batch: the tests build the same batch both ways
-    const int merge_knob = em ? atoi(em) : -1;
-    const bool merge_off = merge_knob == 0 || (merge_knob < 0 && b.work.size() > (size_t)24 * 16 * (size_t)std::max(b.ctx ? b.ctx->n_cu : 256, 1));
+    const bool merge_off = em && em[0] == '0';
     const int nchar = b.has_n ? 5 : 4;
     int prev_mc = 0;
     for (const KLaunch& l : b.launches) {
