@@ -296,6 +296,17 @@ struct DevBuf {
 };
 
 bool valid_base_lut(uint8_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N'; }
+// 1 if some byte of p[0, n) is not one of ACGTN (a table lookup per byte, four independent chains: the five comparisons per byte of
+// valid_base_lut were a third of a batch's parse time)
+int any_invalid_base(const uint8_t* p, size_t n) {
+  struct Lut { uint8_t bad[256]; Lut() { for (int i = 0; i < 256; i++) bad[i] = !valid_base_lut((uint8_t)i); } };
+  static const Lut lut;
+  unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  size_t k = 0;
+  for (; k + 4 <= n; k += 4) { b0 |= lut.bad[p[k]]; b1 |= lut.bad[p[k + 1]]; b2 |= lut.bad[p[k + 2]]; b3 |= lut.bad[p[k + 3]]; }
+  for (; k < n; k++) b0 |= lut.bad[p[k]];
+  return (int)((b0 | b1 | b2 | b3) != 0);
+}
 
 }  // namespace
 
@@ -424,7 +435,7 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
   for (int i = 0; i < n; i++) {
     const SeqRef& r = refs[first + (size_t)i];
     const uint8_t* q = p + (r.off - base_off);
-    for (uint32_t k = 0; k < r.len; k++) bad |= !valid_base_lut(q[k]);
+    bad |= any_invalid_base(q, r.len);
     form[first + (size_t)i] = (uint8_t)phmm_read_form(q, (int)r.len);
   }
   if (bad) return ACCG_ERR_BAD_BASE;
