@@ -1214,8 +1214,8 @@ bool graphs_wanted();
 // workgroups of 20 KB), so the tail's workgroups (22 KB each, empty as they are) cannot start before the next sweep's workgroups
 // retire, and the tail of pass i ends up holding back the sweep of pass i + 2.  Not worth 1.5 %: off.
 bool pipeline_on() {
-  static const bool on = [] { const char* e = getenv("ACCG_PHMM_PIPELINE"); return e && e[0] == '1'; }();
-  return on && !graphs_wanted();
+  const char* e = getenv("ACCG_PHMM_PIPELINE");          // read per pass: the tests run one batch both ways
+  return e && e[0] == '1' && !graphs_wanted();
 }
 void swap_sets(accg_phmm_batch* b) {
   accg_phmm_batch::PassSet cur;

@@ -456,6 +456,37 @@ def test_ring_equals_one_shot(ctx):
                 ring.wait(ts[0], ser[0][2])
 
 
+def test_pipelined_passes_equal_serial_ones(ctx, monkeypatch):
+    """ACCG_PHMM_PIPELINE=1 (off by default): a pass's tail -- planner, fp64 rescue, re-runs -- on the context's tail stream while the
+    next pass's sweep already runs on a second set of pass buffers.  Several passes in a row, modes alternating, then the results
+    of the last one: the same bits as serial passes; switching back and forth between the two ways on one batch works too."""
+    rng = synth.rng_for(370)
+    regs = [synth.make_region(rng, 48, 6, (30, 200), (60, 400), n_frac=0.01, unrelated_frac=0.3) for _ in range(6)]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h)) for r, h in regs]
+    with A.PhmmBatch(ctx, ser) as b:
+        want = {}
+        for mode in (A.ACCG_PHMM_FAST, A.ACCG_PHMM_STRICT):
+            b.run(mode)
+            raw, l10, cnt = b.results()
+            want[mode] = (raw.tobytes(), l10.tobytes(), cnt.rescued)
+        assert want[A.ACCG_PHMM_FAST][2] > 50
+        for knob in ("1", "0", "1"):
+            monkeypatch.setenv("ACCG_PHMM_PIPELINE", knob)
+            for mode in (A.ACCG_PHMM_FAST, A.ACCG_PHMM_FAST, A.ACCG_PHMM_STRICT, A.ACCG_PHMM_FAST, A.ACCG_PHMM_STRICT):
+                b.run(mode)
+            raw, l10, cnt = b.results()
+            assert (raw.tobytes(), l10.tobytes(), cnt.rescued) == want[A.ACCG_PHMM_STRICT]
+            for _ in range(4):
+                b.run(A.ACCG_PHMM_FAST)
+            ctx.synchronize()
+            raw, l10, cnt = b.results()
+            assert (raw.tobytes(), l10.tobytes(), cnt.rescued) == want[A.ACCG_PHMM_FAST]
+            k_ms, step_ms = b.time_in_step(A.ACCG_PHMM_FAST, iters=3)
+            assert 0 < k_ms <= step_ms
+            raw, l10, cnt = b.results()
+            assert (raw.tobytes(), l10.tobytes(), cnt.rescued) == want[A.ACCG_PHMM_FAST]
+
+
 def test_threaded_ring_equals_one_shot(ctx):
     """accg_phmm_ring_create_threaded: the host half of every ticket on a worker thread of its slot.  Same bits as the blocking call,
     single regions and several under one ticket, with every slot busy; a malformed blob whose header passes the submit-time check
