@@ -613,7 +613,8 @@ void partition(accg_phmm_batch& b) {
   const bool dom5 = n_form5 >= n_other;
   struct Eval { double span = -1; bool pays = false; };
   auto evaluate = [&](uint64_t budget, bool sim_pairs) -> Eval {
-    std::map<double, uint64_t, std::greater<double>> hist;
+    std::vector<std::pair<double, uint64_t>> hist;       // (cost, jobs): collected, then sorted by descending cost and merged (a map's
+    hist.reserve(b.regions.size() * 8);                  // node per insertion was most of the search's time)
     std::map<double, uint64_t> loads;
     std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens;
     uint32_t cap = 0, hmax = 1;
@@ -630,7 +631,7 @@ void partition(accg_phmm_batch& b) {
         if (!mult) return;
         for (size_t c = 0; c < lens.size(); c += sim_pairs ? 2 : 1) {
           const uint32_t len = sim_pairs && c + 1 < lens.size() ? std::max(lens[c], lens[c + 1]) : lens[c];
-          hist[(len + 15 + prologue_steps) * (7.0 * lastK + 10.0)] += mult;
+          hist.emplace_back((len + 15 + prologue_steps) * (7.0 * lastK + 10.0), mult);
         }
       };
       for (const Group& Q : groups[ri]) {
@@ -642,6 +643,15 @@ void partition(accg_phmm_batch& b) {
     }
     Eval ev;
     if (n_jobs == 0) return ev;
+    std::sort(hist.begin(), hist.end(), [](const std::pair<double, uint64_t>& x, const std::pair<double, uint64_t>& y) { return x.first > y.first; });
+    {
+      size_t w_ = 0;
+      for (size_t i = 0; i < hist.size(); i++) {
+        if (w_ && hist[w_ - 1].first == hist[i].first) hist[w_ - 1].second += hist[i].second;
+        else hist[w_++] = hist[i];
+      }
+      hist.resize(w_);
+    }
     ev.pays = lpp_dom * K_dom > 16 && pairs_pay(K_dom, nchar, (int)((cap + 63) / 64 * 64), (int)hmax, lpp_dom);
     // Resident wavefronts per CU: what registers and LDS allow, or fewer on purpose.  tools/ubench2.hip: the instruction mix of the
     // sweep issues at 1.32 / 1.34 / 1.26 / 1.07 ns per wave-instruction per SIMD with 2 / 3 / 4 / 8 resident wavefronts and at
