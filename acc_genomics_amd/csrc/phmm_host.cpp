@@ -321,6 +321,7 @@ struct accg_phmm_batch {
   std::vector<uint8_t> streams;  // the haplotype streams of all runs, laid out for the kernels that copy theirs in (phmm_dev.h: PHMM_STREAM_TAIL)
   std::vector<uint32_t> chunk_stream16, chunk_stream_len;   // per run (index into chunks_dev): offset in 16-byte units / length
   uint64_t n_rows = 0;           // read bases in all = per-row records
+  bool redo_possible = false;    // some read's fp64 result may land next to the denormal range (parse_reads: `deep`): the strict re-run launches are needed
   bool all_form5 = true;         // every read passes the five-operation form's range tests: the fp64 rescue pass may use it too
   bool any_form5 = false;        // some launch runs the five-operation sweep: phmm_prepare_rows runs at the start of a fast pass
   std::vector<uint8_t> rd_form;  // per read: the cheapest form of the fast sweep it passes the range tests of: 5, 6 or 7 (phmm_dev.h)
@@ -412,7 +413,14 @@ int phmm_read_form(const uint8_t* p, int len) {
   return all ? 5 : 6;
 }
 
-int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, std::vector<uint8_t>& form) {
+// `deep` (out, or-ed): some read's likelihood may come out within 36 decades of the smallest normal double in the fp64 rescue -- the
+// only case in which the fast mode's strict re-run launch (phmm_redo_multi) can have anything to do.  For every other batch the launch
+// is skipped, by a bound the host can check: against ANY haplotype the forward sum is at least the path "first base in M, all others
+// inserted", summed over the start columns: INIT x dist_min(q[0]) x (1 - ph[qc[0]]) x ph[qi[1]] x prod_{r >= 2} ph[qc[r]] -- i.e.
+// log10(result x 2^1020) >= 307.05 - 1.17 - (q[0] + qi[1] + sum_{r >= 2} qc[r]) / 10 when qc[0] >= 1 (tools/check_floor_bound.py holds
+// it against the oracle).  A sum of at most 5500 leaves the result above 1e-244; the kernels list a job at 1e-280 (PHMM_F64_TINY).
+constexpr uint32_t PHMM_REDO_Q_SUM_MAX = 5500;
+int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, std::vector<uint8_t>& form, bool& deep) {
   if (bytes < 4) return ACCG_ERR_BAD_WIRE;
   int32_t n; memcpy(&n, p, 4);
   if (n < 0) return ACCG_ERR_BAD_WIRE;
@@ -430,15 +438,21 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
   // base validation and the range tests of the sweep's forms, read by read: independent, on the host's threads for a large region
   // (inside the per-region parallel loop of a multi-region batch this stays serial: no nested teams)
   form.resize(first + (size_t)n);
-  int bad = 0;
-#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) reduction(| : bad) if (n >= 512)
+  int bad = 0, dp = 0;
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) reduction(| : bad, dp) if (n >= 512)
   for (int i = 0; i < n; i++) {
     const SeqRef& r = refs[first + (size_t)i];
     const uint8_t* q = p + (r.off - base_off);
     bad |= any_invalid_base(q, r.len);
     form[first + (size_t)i] = (uint8_t)phmm_read_form(q, (int)r.len);
+    const size_t L = r.len;
+    const uint8_t *bq = q + L, *qi = q + 2 * L, *qc = q + 4 * L;
+    uint32_t tq = (uint32_t)(bq[0] & 127) + (L >= 2 ? (uint32_t)(qi[1] & 127) : 0u);
+    for (size_t k = 2; k < L; k++) tq += (uint32_t)(qc[k] & 127);
+    dp |= (int)((qc[0] & 127) == 0 || tq > PHMM_REDO_Q_SUM_MAX);
   }
   if (bad) return ACCG_ERR_BAD_BASE;
+  if (dp) deep = true;
   return n;
 }
 int parse_haps(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<SeqRef>& refs, bool& has_n, std::vector<const uint8_t*>& ptrs) {
@@ -985,6 +999,8 @@ int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
   // Fast mode, every read in the five-operation form's range: the classes with K <= 8 go out as two launches by register budget
   // (phmm_dev.h: PHMM_RESCUE_MERGED) and one strict re-run launch behind both, instead of two launches per class.
   const bool merged = mode != ACCG_PHMM_STRICT && b->all_form5 && !f5_off && !merge_off;
+  // the strict re-run launches: only when some read can reach the range they exist for (parse_reads: `deep`); ACCG_PHMM_REDO_ALWAYS=1: always
+  const bool redo = b->redo_possible || [] { const char* e = getenv("ACCG_PHMM_REDO_ALWAYS"); return e && e[0] == '1'; }();
   const int wg = pairs ? 2 : 1;
   uint64_t win_units[2] = {0, 0};
   size_t win_lds[2] = {0, 0}, redo_lds = 0;
@@ -1028,14 +1044,14 @@ int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
     a.redo_list = strict ? nullptr : b->d_redo.p + b->rescue_off[c];
     ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, strict, phmm_rescue_striped(c), a, b->rescue_off[c], bound, st, PHMM_RESCUE_GRID_DEFAULT,
                                     b->all_form5 && !f5_off, wg));
-    if (!strict) {        // the jobs that launch listed (results next to the denormal range), in the reference's operation order
+    if (!strict && redo) {        // the jobs that launch listed (results next to the denormal range), in the reference's operation order
       PhmmArgs<double> r = a;
       r.job_count = a.redo_count; r.job_map = a.redo_list; r.redo_count = nullptr; r.redo_list = nullptr; r.is_redo = 1;
       ACCG_HIP(phmm_launch_rescue_f64(k_c, lpp_c, true, phmm_rescue_striped(c), r, b->rescue_off[c], bound, st, PHMM_REDO_GRID));
     }
   }
   if (fork) ACCG_HIP(on_tail ? ctx_join_tail(b->ctx) : ctx_join(b->ctx));
-  if (win_units[0] || win_units[1]) {     // behind both windows: the items they listed, in the reference's operation order
+  if ((win_units[0] || win_units[1]) && redo) {     // behind both windows: the items they listed, in the reference's operation order
     PhmmArgs<double> r = a;
     r.job_count = nullptr; r.job_map = nullptr; r.is_redo = 1;
     r.redo_count = b->d_state.p + state_redo(*b); r.redo_list = b->d_redo.p;
@@ -1063,14 +1079,14 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   if (roff >= (1ull << 32) || hoff >= (1ull << 32)) return ACCG_ERR_TOO_LONG;   // 32-bit blob offsets
   // Regions are parsed (lengths, base validation, the range tests of the sweep's forms) independently of each other, on the host
   // threads this process may use when there are enough of them, and merged in order.
-  struct Parsed { std::vector<SeqRef> rd, hp; std::vector<uint8_t> form; std::vector<const uint8_t*> hp_ptr; bool has_n = false; int nr = 0, nh = 0; };
+  struct Parsed { std::vector<SeqRef> rd, hp; std::vector<uint8_t> form; std::vector<const uint8_t*> hp_ptr; bool has_n = false, deep = false; int nr = 0, nh = 0; };
   std::vector<Parsed> parsed((size_t)n_regions);
   std::vector<uint64_t> roffs((size_t)n_regions + 1, 0), hoffs((size_t)n_regions + 1, 0);
   for (int i = 0; i < n_regions; i++) { roffs[i + 1] = roffs[i] + reads_bytes[i]; hoffs[i + 1] = hoffs[i] + haps_bytes[i]; }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (n_regions >= 8)
   for (int i = 0; i < n_regions; i++) {
     Parsed& P = parsed[i];
-    P.nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roffs[i], P.rd, P.form);
+    P.nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roffs[i], P.rd, P.form, P.deep);
     if (P.nr >= 0) P.nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoffs[i], P.hp, P.has_n, P.hp_ptr);
   }
   for (int i = 0; i < n_regions; i++) {
@@ -1084,6 +1100,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     for (uint8_t f : P.form) b->all_form5 &= f == 5;
     b->hp.insert(b->hp.end(), P.hp.begin(), P.hp.end()); b->hp_ptr.insert(b->hp_ptr.end(), P.hp_ptr.begin(), P.hp_ptr.end());
     b->has_n |= P.has_n;
+    b->redo_possible |= P.deep;
     r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;
     uint64_t rsum = 0, hsum = 0;
     for (int k = 0; k < nr; k++) rsum += b->rd[r.read0 + k].len;

@@ -456,6 +456,29 @@ def test_ring_equals_one_shot(ctx):
                 ring.wait(ts[0], ser[0][2])
 
 
+def test_skipped_rerun_launch_changes_nothing(ctx, monkeypatch):
+    """The strict re-run launch of the fast mode's rescue is skipped when the host can prove that no read's fp64 result comes near the
+    denormal range (phmm_host.cpp: parse_reads, `deep`; the bound: tools/check_floor_bound.py).  Regions of unrelated reads of 150 to
+    520 bases straddle that decision; with the launch forced (ACCG_PHMM_REDO_ALWAYS=1) every region gives the same bits, and the fast
+    mode stays within tolerance of the strict one."""
+    rng = synth.rng_for(380)
+    for lo, hi in ((150, 300), (380, 470), (480, 520)):
+        reads, haps = synth.make_region(rng, 12, 4, (lo, hi), (hi, hi + 200), unrelated_frac=0.8)
+        ser = [(synth.serialize_reads(reads), synth.serialize_haps(haps))]
+        got = []
+        for knob in ("0", "1"):
+            monkeypatch.setenv("ACCG_PHMM_REDO_ALWAYS", knob)
+            with A.PhmmBatch(ctx, ser) as b:
+                b.run(A.ACCG_PHMM_FAST)
+                raw, l10, cnt = b.results()
+                b.run(A.ACCG_PHMM_STRICT)
+                _, want, _ = b.results()
+            assert cnt.rescued > 20
+            assert np.max(np.abs(l10 - want) / np.abs(want)) < REL_TOL
+            got.append((raw.tobytes(), l10.tobytes(), cnt.rescued))
+        assert got[0] == got[1]
+
+
 def test_pipelined_passes_equal_serial_ones(ctx, monkeypatch):
     """ACCG_PHMM_PIPELINE=1 (off by default): a pass's tail -- planner, fp64 rescue, re-runs -- on the context's tail stream while the
     next pass's sweep already runs on a second set of pass buffers.  Several passes in a row, modes alternating, then the results
