@@ -1705,7 +1705,8 @@ extern "C" int accg_phmm_ring_submit_many(accg_phmm_ring* r, int n_regions, cons
                                           const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t* ticket) {
   if (!r || !ticket || n_regions < 1 || !reads_ser || !reads_bytes || !haps_ser || !haps_bytes) return ACCG_ERR_BAD_ARG;
   const size_t slot = (size_t)(r->next_ticket % r->ctx.size());
-  if (r->batch[slot] || (r->threaded && r->slot[slot]->busy)) return ACCG_ERR_BAD_ARG;    // the slot's previous ticket has not been waited for
+  // the slot's previous ticket has not been waited for (a threaded slot's batch pointer belongs to its worker while a ticket is out)
+  if (r->threaded ? r->slot[slot]->busy : r->batch[slot] != nullptr) return ACCG_ERR_BAD_ARG;
   uint64_t pairs = 0; size_t blob = 0;
   for (int i = 0; i < n_regions; i++) {
     if (reads_bytes[i] < 4 || haps_bytes[i] < 4 || !reads_ser[i] || !haps_ser[i]) return ACCG_ERR_BAD_WIRE;
