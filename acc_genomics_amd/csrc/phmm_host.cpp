@@ -1616,7 +1616,14 @@ static int ring_submit_body(accg_phmm_ring* r, size_t slot, int n_regions, const
                             const void* const* haps_ser, const size_t* haps_bytes, int mode, uint64_t pairs, size_t blob);
 static void ring_worker(accg_phmm_ring* r, size_t slot) {
   RingSlot& S = *r->slot[slot];
-  tls_host_threads = 1;                       // no team of its own: the workers ARE the host's parallelism
+  // the worker's share of the host's threads: with few slots each worker keeps a small team for the parallel loops of batch creation,
+  // with as many slots as threads the workers ARE the parallelism (ACCG_RING_WORKER_THREADS overrides)
+  {
+    const char* e = getenv("ACCG_RING_WORKER_THREADS");
+    const int all = host_threads();
+    tls_host_threads = e && atoi(e) > 0 ? atoi(e) : std::max(1, all / (int)r->ctx.size());
+    if (!getenv("KMP_BLOCKTIME")) kmp_set_blocktime(1);      // (per thread: see accg_init)
+  }
   for (;;) {
     std::unique_lock<std::mutex> lk(S.mu);
     S.cv.wait(lk, [&] { return S.has_work || S.quit; });
