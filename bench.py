@@ -476,6 +476,22 @@ def bench_c3(ctx, comm, steps, warmup, mode, with_cpu):
                "per_rank": [{"rank": r["rank"], "regions": r["regions"], "cells": r["cells"], "kernel_ms": r["kernel_ns"] / 1e6,
                              "ms_per_step": r["wall_s"] / steps * 1e3, "rescued": r["rescued"]} for r in per_rank],
                "setup_s": time.perf_counter() - t_gen - wall}
+        # the dominant kernel of this leg on rank 0's shard: the merged fp32 sweep, timed inside whole passes like the headline's
+        try:
+            k_ms, s_ms = batch.time_in_step(mode, 5)
+            shard_cells = batch.cells
+            tj = traffic().get("phmm_c3_sweep")
+            rf = {"bound": "fp32 VALU issue", "kernel": "phmm_kernel_multi<6,13,2>: every (lanes, K) class of the five-operation sweep in one launch",
+                  "kernel_ms": k_ms, "kernel_ms_how": "HIP events around the sweep launch inside 5 whole passes over rank 0's shard (accg_phmm_batch_time_in_step); those passes took %.4f ms each" % s_ms,
+                  "cells_per_launch": shard_cells, "valu_frac": 12.0 * shard_cells / (k_ms * 1e-3) / 157.3e12,
+                  "achieved": 12.0 * shard_cells / (k_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": 12.0 * shard_cells / (k_ms * 1e-3) / 157.3e12,
+                  "note": "12 algorithmic flop per cell (baseline_impl.cpp:84-86) against the fp32 vector peak; instruction counts of this kernel: profiles/r03_pmc_c3.txt"}
+            if tj and tj.get("valu_insts_per_launch") and comm.world == 1:
+                rf["issue_frac"] = tj["valu_insts_per_launch"] / 1024.0 * 2.0 / 2.4e9 / (k_ms * 1e-3)
+                rf["pmc_source"] = pmc_source()
+            out["roofline"] = rf
+        except Exception as e:                      # (the instrument must not cost the leg its line)
+            out["roofline"] = {"error": str(e)}
         if with_cpu:
             import orc
             O = orc.oracle()

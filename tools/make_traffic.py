@@ -43,6 +43,23 @@ if bw:
     bw["valu_insts_per_pass"] = (bw["valu_insts_per_launch"] or 0) * bw_launches
     out["bwasw"] = bw
 out = {k: v for k, v in out.items() if v}
+# the kernels of a configs[3] pass (tools/prof_pmc_cmd.sh over tools/run_c3.py 1024: profiles/*_pmc_c3.txt), when measured
+for name in sorted(os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))):
+    if not name.endswith("_pmc_c3.txt"):
+        continue
+    blocks, cur = {}, None
+    for line in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)):
+        if line.startswith("== "):
+            cur = line[3:].strip(); blocks[cur] = {}
+        elif cur and "(n=" in line:
+            f = line.split()
+            blocks[cur][f[0]] = float(f[1])
+    for key, blk in (("phmm_c3_sweep", "phmm_kernel_multi"), ("phmm_c3_rescue_k_le_5", "phmm_rescue_multi<0"), ("phmm_c3_rescue_k_6_8", "phmm_rescue_multi<1")):
+        v = blocks.get(blk)
+        if v and v.get("SQ_INSTS_VALU"):
+            out[key] = {"source": "profiles/" + name, "valu_insts_per_launch": v["SQ_INSTS_VALU"],
+                        "hbm_bytes_per_launch": (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0,
+                        "counters": {c: v[c] for c in KEEP if c in v}, "note": "1024-region configs[3] batch, one launch per pass"}
 # lookups the SMEM kernel really performs on configs[4] (tools/smem_counts.py, the -DSMEM_COUNT build), when measured
 root_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for name in sorted(os.listdir(os.path.join(root_, "profiles")), reverse=True):
