@@ -67,6 +67,9 @@ struct accg_ctx {
   // a slot of an accg_phmm_ring: batch creation does not wait for its upload (the staging block is the slot's own and is not
   // touched again before the slot's results have been fetched)
   bool async_create = false;
+  int wall_khz = 100000;        // rate of the device's constant wall clock (wall_clock64): 100 MHz on every gfx9
+  // uploads and result blocks up to this size travel by copy kernels on the stream instead of hipMemcpyAsync (ACCG_COPY_KERNEL_MAX, bytes; 0 = never)
+  size_t kernel_copy_max = 2u << 20;
   // Independent kernels of one pass (one launch per rows-per-lane class) are spread over these streams, forked from and
   // joined back to `stream`: queued on one stream each launch would wait for the previous one's last wavefront.
   static constexpr int N_AUX = 4;
@@ -93,4 +96,7 @@ hipError_t ctx_fork_tail(accg_ctx* c);       // the same for the tail stream and
 hipError_t ctx_join_tail(accg_ctx* c);
 hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p);   // pinned staging of at least `bytes`
 hipError_t ctx_join(accg_ctx* c);
+// transfers of a small batch as kernels on its stream (util_kernels.hip); host_pinned / stage_pinned: the context's staging block
+hipError_t upload_by_kernel(const void* host_pinned, void* dev, size_t bytes, unsigned long long* tick, hipStream_t s);
+hipError_t phmm_results_by_kernel(const void* res, const double* out64, size_t n, void* stage_pinned, size_t off64_bytes, const unsigned long long* tick, hipStream_t s);
 }  // namespace accg

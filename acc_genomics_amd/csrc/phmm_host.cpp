@@ -49,6 +49,15 @@ extern "C" const char* accg_strerror(int st) {
 }
 
 // ---- context ------------------------------------------------------------------------------------
+// libomp only (the symbol is weak: a host built against another OpenMP runtime links and simply keeps its setting); per calling thread;
+// KMP_BLOCKTIME in the environment wins, ACCG_KEEP_OMP_BLOCKTIME=1 leaves the host application's setting alone
+#pragma weak kmp_set_blocktime
+namespace accg {
+void omp_short_blocktime() {
+  static const bool keep = getenv("KMP_BLOCKTIME") != nullptr || (getenv("ACCG_KEEP_OMP_BLOCKTIME") && getenv("ACCG_KEEP_OMP_BLOCKTIME")[0] == '1');
+  if (!keep && &kmp_set_blocktime != nullptr) kmp_set_blocktime(1);
+}
+}  // namespace accg
 extern "C" int accg_init(int device, accg_ctx** out) {
   if (!out) return ACCG_ERR_BAD_ARG;
   *out = nullptr;
@@ -61,13 +70,15 @@ extern "C" int accg_init(int device, accg_ctx** out) {
   // The host loops' OpenMP threads go to sleep a millisecond after a parallel region instead of libomp's 200 ms of spinning: under a
   // CPU quota (a container's share of a large host) spinners eat the quota the working threads need (a threaded ring next to a
   // 16-thread team measured 30 ms for a stream that takes 7).  KMP_BLOCKTIME in the environment wins.
-  if (!getenv("KMP_BLOCKTIME")) kmp_set_blocktime(1);
+  omp_short_blocktime();
   // a failure below hands the half-built context to accg_shutdown (streams, events, tables made so far are released)
   struct Guard { accg_ctx* c; ~Guard() { if (c) accg_shutdown(c); } } guard{new accg_ctx};
   accg_ctx* c = guard.c;
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, c->n_cu);
+  { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_khz = khz; }
+  if (const char* e = getenv("ACCG_COPY_KERNEL_MAX")) c->kernel_copy_max = (size_t)strtoull(e, nullptr, 10);
   ACCG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   ACCG_HIP(hipEventCreate(&c->ev0));
   ACCG_HIP(hipEventCreate(&c->ev1));
@@ -192,7 +203,8 @@ int host_threads() {
 }
 hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p) {
   if (bytes > c->h_stage_bytes) {
-    if (c->h_stage) hipHostFree(c->h_stage);
+    // (a copy kernel queued on the context's stream may still be reading the block that is about to go)
+    if (c->h_stage) { hipError_t es = hipStreamSynchronize(c->stream); if (es != hipSuccess) return es; hipHostFree(c->h_stage); }
     c->h_stage = nullptr; c->h_stage_bytes = 0;
     const size_t cap = std::max<size_t>((bytes + (1u << 20) - 1) >> 20 << 20, 1u << 20);
     hipError_t e = hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault);
@@ -373,7 +385,9 @@ struct accg_phmm_batch {
   // One pass = memset + a launch per (lanes, K) class on forked streams + rescue plan + the rescue classes and their strict
   // re-runs: captured once per arithmetic mode into a graph and replayed (every argument is fixed at batch creation).
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  bool kernel_copies = false;    // a small batch: upload and results travel by copy kernels on the stream (accg_ctx::kernel_copy_max)
   bool results_late = false;     // ring: the downloads are queued by results_finish, not behind the kernels
+  bool results_fetched = false;  // the raw results (and, for kernel copies, the fp64 values) of the last pass are in the staging block
   bool graph_off = false;        // capture failed once, or ACCG_PHMM_GRAPH=0: plain stream launches
 };
 
@@ -498,6 +512,11 @@ bool pairs_pay(int K, int nchar, int stream_cap, int haps_cap, int lpp) {
 int pinned_wpc(int natural) { return natural >= 32 ? 32 : natural >= 16 ? 16 : natural >= 8 ? 8 : natural; }
 
 struct Chunk { uint32_t ids0, n; uint32_t stream_len; };
+
+// A pass's results in the context's pinned staging: [device ticks u64][n_rescued u64][raw f32 x pairs][pad to 8][fp64 x pairs]
+constexpr size_t RES_HDR = 2 * sizeof(unsigned long long);
+size_t results_off64(uint64_t pairs) { return (RES_HDR + pairs * sizeof(float) + 7) / 8 * 8; }
+size_t results_stage_bytes(uint64_t pairs) { return results_off64(pairs) + pairs * sizeof(double) + 64; }
 
 // Greedy runs of haplotypes with at most `budget` stream entries (a single longer haplotype gets a run of its own).
 void chunk_region(const accg_phmm_batch& b, const Region& r, uint64_t budget, std::vector<std::pair<uint32_t, uint32_t>>& runs,
@@ -941,7 +960,7 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
   a.clock_out = reinterpret_cast<unsigned long long*>(b->d_clock.p);
   if (ev_begin) ACCG_HIP(hipEventRecord(ev_begin, b->ctx->stream));
   const std::vector<KLaunch>& launches = mode == ACCG_PHMM_STRICT ? b->launches : b->launches_fast;
-  const bool fork = launches.size() > 1;          // several rows-per-lane classes: run them side by side
+  const bool fork = launches.size() > 1 && !(b->kernel_copies && launches.size() <= 2);   // several rows-per-lane classes: run them side by side
   if (fork) ACCG_HIP(ctx_fork(b->ctx));
   for (const KLaunch& l : launches) {
     a.stream_cap = l.stream_cap; a.haps_cap = l.haps_cap;
@@ -1016,7 +1035,9 @@ int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
     redo_lds = std::max(redo_lds, phmm_lds_bytes(k_c, 8, a.nchar, a.stream_cap, a.haps_cap, lpp_c, false, false, 1));
   }
   n_launch += (win_units[0] != 0) + (win_units[1] != 0);
-  const bool fork = n_launch > 1;
+  // (a small batch -- the blocking call per region -- queues its few, short rescue launches one behind the other: the events of a fork
+  // and a join cost it more than the launches overlapping could save)
+  const bool fork = n_launch > 1 && !b->kernel_copies;
   if (fork) ACCG_HIP(on_tail ? ctx_fork_tail(b->ctx) : ctx_fork(b->ctx));
   int rr = 0;
   PhmmRescueSet rs;
@@ -1205,7 +1226,11 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   memset(stage + o_streams + b->streams.size(), 0, 16);
   b->hp_ptr.clear(); b->hp_ptr.shrink_to_fit();            // the caller's blobs are not ours beyond this call
   const auto tq3 = std::chrono::steady_clock::now();
-  if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
+  // a small batch goes over by a copy kernel on its stream (no DMA engine in the chain: util_kernels.hip), which also notes the device's
+  // wall clock at the start of the batch's device work (accg_phmm_region reports the device time from it)
+  b->kernel_copies = upload_bytes + 16 <= ctx->kernel_copy_max && results_stage_bytes(b->pairs) <= ctx->kernel_copy_max;
+  if (upload_bytes && b->kernel_copies) ACCG_HIP(upload_by_kernel(stage, base, upload_bytes, reinterpret_cast<unsigned long long*>(b->d_clock.p) + 2, s));
+  else if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
   const auto tq4 = std::chrono::steady_clock::now();
   // out64, state, out start at zero: cleared by the kernel that writes the per-row records of the five-operation sweep (phmm_dev.h:
   // PhmmRowRecs, from the uploaded reads) when there is one -- a hipMemsetAsync of a megabyte or two costs the host 100 to 150 us
@@ -1431,49 +1456,82 @@ extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, in
 namespace {
 // results of a pass in two halves for the ring: the device-to-host copies queued behind the kernels (both result arrays, always),
 // and the host half -- wait, log10 (same libm as the reference) -- when the caller comes for them
-size_t results_stage_bytes(uint64_t pairs) { return (sizeof(unsigned long long) + pairs * sizeof(float) + 7) / 8 * 8 + pairs * sizeof(double) + 64; }
+// Where one region's share of a pass's results goes (a batch's results are concatenated in region order)
+struct ResultDst { float* raw; double* l10; accg_counters* cnt; uint64_t pairs, cells; };
 // The downloads of a ticket: queued behind its kernels at once (plain ring: one caller thread, nothing else submits meanwhile), or
 // -- threaded ring, `late` -- only when the kernels have finished: a copy that sits in a DMA queue waiting for a kernel blocks the
 // NEXT copy submitted to that queue, another slot's upload, inside hipMemcpyAsync on that slot's worker (measured: creations of
-// 1.7 ms took 7 to 11 ms while the device worked through the tickets ahead).
+// 1.7 ms took 7 to 11 ms while the device worked through the tickets ahead).  A small batch (kernel_copies) sends its results by a
+// copy kernel instead, which is queued at once either way: it involves no DMA queue.
 int results_enqueue(accg_phmm_batch* b, bool late) {
   { const int stj = join_tail(b); if (stj != ACCG_OK) return stj; }
-  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
+  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), off64 = results_off64(n);
   void* stage_v = nullptr;
-  ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));      // (sized by the submitter before the upload: no reallocation here)
-  b->results_late = late;
-  if (late) return ACCG_OK;
+  ACCG_HIP(ctx_stage(b->ctx, results_stage_bytes(n), &stage_v));      // (sized by the submitter before the upload: no reallocation here)
   uint8_t* stage = (uint8_t*)stage_v;
-  ACCG_HIP(hipMemcpyAsync(stage, b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
-  if (n) ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+  if (b->kernel_copies) {
+    b->results_late = false; b->results_fetched = true;
+    ACCG_HIP(phmm_results_by_kernel(b->res_ptr, b->d_out64.p, n, stage, off64, reinterpret_cast<unsigned long long*>(b->d_clock.p) + 2, b->ctx->stream));
+    return ACCG_OK;
+  }
+  b->results_late = late; b->results_fetched = false;
+  if (late) return ACCG_OK;
+  memset(stage, 0, sizeof(unsigned long long));
+  ACCG_HIP(hipMemcpyAsync(stage + sizeof(unsigned long long), b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
+  if (n) ACCG_HIP(hipMemcpyAsync(stage + off64, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+  b->results_fetched = true;
+  return ACCG_OK;
+}
+// waits for the pass, fetches what results_enqueue has not, and hands every region's share to its destination (raw copy, log10 as
+// FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190 take it, counters)
+int results_finish(accg_phmm_batch* b, const ResultDst* dst, size_t n_dst) {
+  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), off64 = results_off64(n);
+  uint8_t* stage = (uint8_t*)b->ctx->h_stage;
+  if (!b->results_fetched) {
+    memset(stage, 0, sizeof(unsigned long long));
+    ACCG_HIP(hipMemcpyAsync(stage + sizeof(unsigned long long), b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
+    ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  }
+  unsigned long long nresc = 0, ticks = 0;
+  memcpy(&ticks, stage, sizeof ticks);
+  memcpy(&nresc, stage + sizeof ticks, sizeof nresc);
+  if (b->kernel_copies && ticks) b->last_kernel_ns = (uint64_t)((double)ticks * 1e6 / (double)b->ctx->wall_khz);
+  const float* raw = (const float*)(stage + RES_HDR);
+  const double* r64 = (const double*)(stage + off64);
+  bool want_l10 = false;
+  for (size_t d = 0; d < n_dst; d++) want_l10 |= dst[d].l10 != nullptr;
+  if (want_l10 && n && nresc && !b->results_fetched) {              // the fp64 values only when something was rescued
+    ACCG_HIP(hipMemcpyAsync(stage + off64, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
+  }
+  b->results_fetched = true;
+  const HostTables& t = host_tables();
+  size_t o = 0;
+  for (size_t d = 0; d < n_dst; d++) {
+    const ResultDst& D = dst[d];
+    const size_t m = (size_t)D.pairs;
+    if (o + m > n) return ACCG_ERR_BAD_ARG;
+    if (D.raw && m) memcpy(D.raw, raw + o, m * sizeof(float));
+    if (D.l10 && m) {
+      double* out_log10 = D.l10; const float* rw = raw + o; const double* rd = r64 + o;
+      // (a log10f per pair is 10 ns: half a millisecond for a ticket of 32 configs[3] regions on one thread)
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (m >= 16384 && accg::host_threads() > 1)
+      for (size_t i = 0; i < m; i++)
+        out_log10[i] = rw[i] < PHMM_MIN_ACCEPTED ? log10(rd[i]) - t.log10_init_d : (double)(log10f(rw[i]) - t.log10_init_f);
+    }
+    if (D.cnt) {
+      uint64_t resc = nresc;
+      if (n_dst > 1) { resc = 0; for (size_t i = 0; i < m; i++) resc += raw[o + i] < PHMM_MIN_ACCEPTED; }      // this region's share
+      D.cnt->cells = D.cells; D.cnt->pairs = m; D.cnt->kernel_ns = b->last_kernel_ns; D.cnt->rescued = resc;
+    }
+    o += m;
+  }
   return ACCG_OK;
 }
 int results_finish(accg_phmm_batch* b, float* out_raw, double* out_log10, accg_counters* cnt) {
-  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float), head_al = (head + 7) / 8 * 8;
-  uint8_t* stage = (uint8_t*)b->ctx->h_stage;
-  if (b->results_late) {
-    ACCG_HIP(hipMemcpyAsync(stage, b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
-    ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-  }
-  unsigned long long nresc = 0;
-  memcpy(&nresc, stage, sizeof nresc);
-  const float* raw = (const float*)(stage + sizeof nresc);
-  const double* r64 = (const double*)(stage + head_al);
-  if (out_raw && n) memcpy(out_raw, raw, n * sizeof(float));
-  if (out_log10 && n) {
-    if (nresc && b->results_late) {              // the fp64 values only when something was rescued
-      ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
-      ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-    }
-    const HostTables& t = host_tables();
-    // (a log10f per pair is 10 ns: half a millisecond for a ticket of 32 configs[3] regions on one thread)
-#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n >= 16384 && accg::host_threads() > 1)
-    for (size_t i = 0; i < n; i++)             // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
-      out_log10[i] = raw[i] < PHMM_MIN_ACCEPTED ? log10(r64[i]) - t.log10_init_d : (double)(log10f(raw[i]) - t.log10_init_f);
-  }
-  if (cnt) { cnt->cells = b->cells; cnt->pairs = b->pairs; cnt->kernel_ns = b->last_kernel_ns; cnt->rescued = nresc; }
-  return ACCG_OK;
+  const ResultDst d{out_raw, out_log10, cnt, b->pairs, b->cells};
+  return results_finish(b, &d, 1);
 }
 }  // namespace
 
@@ -1481,35 +1539,17 @@ extern "C" int accg_phmm_batch_results(accg_phmm_batch* b, float* out_raw, doubl
   if (!b) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
   { const int stj = join_tail(b); if (stj != ACCG_OK) return stj; }
-  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-  // one copy: [n_rescued][out f32]; a second one for the fp64 values only when something was rescued
-  const size_t n = b->pairs, head = sizeof(unsigned long long) + n * sizeof(float);
-  const size_t head_al = (head + 7) / 8 * 8;
+  // (a device-resident batch that is run many times: the results are fetched when they are asked for, the fp64 values only when
+  // something was rescued)
   void* stage_v = nullptr;
-  ACCG_HIP(ctx_stage(b->ctx, head_al + n * sizeof(double), &stage_v));
-  uint8_t* stage = (uint8_t*)stage_v;
-  ACCG_HIP(hipMemcpyAsync(stage, b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
-  ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-  unsigned long long nresc = 0;
-  memcpy(&nresc, stage, sizeof nresc);
-  const float* raw = (const float*)(stage + sizeof nresc);
-  if (out_raw && n) memcpy(out_raw, raw, n * sizeof(float));
-  if (out_log10 && n) {
-    const double* r64 = (const double*)(stage + head_al);
-    if (nresc) {
-      ACCG_HIP(hipMemcpyAsync(stage + head_al, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
-      ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
-    }
-    const HostTables& t = host_tables();
-    // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
-#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n > 4096)
-    for (int64_t i = 0; i < (int64_t)n; i++) {
-      if (raw[i] < PHMM_MIN_ACCEPTED) out_log10[i] = log10(r64[i]) - t.log10_init_d;
-      else out_log10[i] = (double)(log10f(raw[i]) - t.log10_init_f);
-    }
-  }
-  if (cnt) { cnt->cells = b->cells; cnt->pairs = b->pairs; cnt->kernel_ns = b->last_kernel_ns; cnt->rescued = nresc; }
-  return ACCG_OK;
+  ACCG_HIP(ctx_stage(b->ctx, results_stage_bytes(b->pairs), &stage_v));
+  b->results_late = true; b->results_fetched = false;
+  const uint64_t keep_ns = b->last_kernel_ns;
+  const bool kc = b->kernel_copies;
+  b->kernel_copies = false;            // (the device clock note belongs to creation, not to this pass)
+  const int st = results_finish(b, out_raw, out_log10, cnt);
+  b->kernel_copies = kc; b->last_kernel_ns = keep_ns;
+  return st;
 }
 
 extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
@@ -1540,40 +1580,76 @@ extern "C" int accg_phmm_region_f64(accg_ctx* ctx, const void* reads_ser, size_t
   return st;
 }
 
-extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
-                                size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* cnt) {
+namespace {
+// pairs and blob bytes of regions as their headers announce them (the staging is sized from these before anything is queued)
+int peek_regions(int n_regions, const void* const* reads_ser, const size_t* reads_bytes, const void* const* haps_ser, const size_t* haps_bytes,
+                 uint64_t* pairs, size_t* blob) {
+  *pairs = 0; *blob = 0;
+  for (int i = 0; i < n_regions; i++) {
+    if (reads_bytes[i] < 4 || haps_bytes[i] < 4 || !reads_ser[i] || !haps_ser[i]) return ACCG_ERR_BAD_WIRE;
+    int32_t nr = 0, nh = 0;
+    memcpy(&nr, reads_ser[i], 4); memcpy(&nh, haps_ser[i], 4);
+    if (nr < 0 || nh < 0) return ACCG_ERR_BAD_WIRE;
+    *pairs += (uint64_t)nr * (uint64_t)nh; *blob += reads_bytes[i] + haps_bytes[i];
+  }
+  return ACCG_OK;
+}
+// One blocking pass over regions handed over together: create (no wait for the upload: the staging block is sized up front and not
+// touched again before the results are in), run, results -- ONE wait for the device in the whole call.
+int region_call(accg_ctx* ctx, int n_regions, const void* const* rs, const size_t* rb, const void* const* hs, const size_t* hb, int mode,
+                const ResultDst* dst_in, size_t n_dst, float* out_raw, double* out_log10, accg_counters* cnt) {
   static const bool trace = getenv("ACCG_TRACE") != nullptr;     // stage timings of the one-shot path on stderr
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
+  if (!ctx) return ACCG_ERR_NOT_INITIALISED;
+  uint64_t pairs = 0; size_t blob = 0;
+  int st = peek_regions(n_regions, rs, rb, hs, hb, &pairs, &blob);
+  if (st != ACCG_OK) return st;
+  ACCG_HIP(hipSetDevice(ctx->device));
+  void* stage = nullptr;
+  ACCG_HIP(ctx_stage(ctx, std::max(results_stage_bytes(pairs), 3 * blob + ((size_t)1 << 20)), &stage));
   accg_phmm_batch* b = nullptr;
-  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
-  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
-  int st = accg_phmm_batch_create(ctx, 1, rs, rb, hs, hb, &b);
+  const bool was_async = ctx->async_create;
+  ctx->async_create = true;
+  st = accg_phmm_batch_create(ctx, n_regions, rs, rb, hs, hb, &b);
+  ctx->async_create = was_async;
   if (st != ACCG_OK) return st;
   const auto t1 = clk::now();
-  hipEventRecord(ctx->ev0, ctx->stream);
+  const bool events = !b->kernel_copies;           // a small batch times itself on the device's wall clock (results_finish)
+  if (events) hipEventRecord(ctx->ev0, ctx->stream);
   b->graph_off = true;            // a single pass: capturing and instantiating a graph would cost more than it saves
   st = accg_phmm_batch_run(b, mode);
   if (st == ACCG_OK) st = join_tail(b);
-  hipEventRecord(ctx->ev1, ctx->stream);
-  auto t2 = t1, t3 = t1;
+  if (events) hipEventRecord(ctx->ev1, ctx->stream);
+  if (st == ACCG_OK) st = results_enqueue(b, false);
+  auto t2 = clk::now(), t3 = t2;
   if (st == ACCG_OK) {
-    if (hipEventSynchronize(ctx->ev1) == hipSuccess) {
+    if (events && hipEventSynchronize(ctx->ev1) == hipSuccess) {
       float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
       b->last_kernel_ns = (uint64_t)((double)ms * 1e6);
     }
-    t2 = clk::now();
-    st = accg_phmm_batch_results(b, out_raw, out_log10, cnt);
+    ResultDst one{out_raw, out_log10, cnt, b->pairs, b->cells};
+    if (!dst_in) { dst_in = &one; n_dst = 1; }
+    if (trace) { hipStreamSynchronize(ctx->stream); t2 = clk::now(); }
+    st = results_finish(b, dst_in, n_dst);
     t3 = clk::now();
   }
-  const uint64_t kernel_ns = b->last_kernel_ns, pairs = b->pairs;
+  const uint64_t kernel_ns = b->last_kernel_ns;
   accg_phmm_batch_destroy(b);
   if (trace) {
     auto us = [](clk::time_point a, clk::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
-    fprintf(stderr, "accg_phmm_region: %llu pairs: create %.0f us, run+wait %.0f us (kernels %.0f us), results %.0f us, destroy %.0f us\n",
+    fprintf(stderr, "accg_phmm_region: %llu pairs: create %.0f us, run+wait %.0f us (device %.0f us), results %.0f us, destroy %.0f us\n",
             (unsigned long long)pairs, us(t0, t1), us(t1, t2), kernel_ns / 1e3, us(t2, t3), us(t3, clk::now()));
   }
   return st;
+}
+}  // namespace
+
+extern "C" int accg_phmm_region(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser,
+                                size_t haps_bytes, int mode, float* out_raw, double* out_log10, accg_counters* cnt) {
+  const void* rs[1] = {reads_ser}; const void* hs[1] = {haps_ser};
+  size_t rb[1] = {reads_bytes}, hb[1] = {haps_bytes};
+  return region_call(ctx, 1, rs, rb, hs, hb, mode, nullptr, 0, out_raw, out_log10, cnt);
 }
 
 
@@ -1622,7 +1698,7 @@ static void ring_worker(accg_phmm_ring* r, size_t slot) {
     const char* e = getenv("ACCG_RING_WORKER_THREADS");
     const int all = host_threads();
     tls_host_threads = e && atoi(e) > 0 ? atoi(e) : std::max(1, all / (int)r->ctx.size());
-    if (!getenv("KMP_BLOCKTIME")) kmp_set_blocktime(1);      // (per thread: see accg_init)
+    omp_short_blocktime();      // (per thread: see accg_init)
   }
   for (;;) {
     std::unique_lock<std::mutex> lk(S.mu);

@@ -1,4 +1,5 @@
 // Small device utilities of the context (not part of any hot path).
+#include <algorithm>
 #include "accg_internal.h"
 
 namespace {
@@ -17,7 +18,41 @@ __global__ __launch_bounds__(256) void clock_probe(unsigned long long spin_ticks
   if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
   if (a == 123.456f) *sink = a;      // keeps the fma chain alive
 }
+// Small transfers as kernels on the stream of the work they belong to: a hipMemcpyAsync between pinned host memory and the device goes
+// through a DMA engine and costs the stream a cross-engine dependency each way (tools/ubench_latency.hip: upload of 80 KB + two kernels +
+// 24 KB back + wait = 29.7 us with copies, 20.9 us with copy kernels) -- for a region of a few thousand pairs that is a tenth of the call.
+__global__ __launch_bounds__(256) void k_upload16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, unsigned long long* tick) {
+  if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick = wall_clock64();
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// results of a PairHMM pass into pinned host memory: [ticks since *tick u64][n_rescued u64][raw f32 x n][pad to 8][fp64 x n, only when
+// something was rescued]; res = the device's [n_rescued u64][raw f32 x n] block
+__global__ __launch_bounds__(256) void k_phmm_results(const uint32_t* __restrict__ res, const uint32_t* __restrict__ out64, size_t n, uint32_t* __restrict__ stage,
+                                                      size_t off64_words, const unsigned long long* tick) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long t = tick ? wall_clock64() - *tick : 0ull;
+    stage[0] = (uint32_t)t; stage[1] = (uint32_t)(t >> 32);
+  }
+  const size_t head = 2 + n, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < head; i += stride) stage[2 + i] = res[i];
+  if ((res[0] | res[1]) != 0u)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 2 * n; i += stride) stage[off64_words + i] = out64[i];
+}
 }  // namespace
+
+namespace accg {
+hipError_t upload_by_kernel(const void* host_pinned, void* dev, size_t bytes, unsigned long long* tick, hipStream_t s) {
+  const size_t n16 = (bytes + 15) / 16;          // (both blocks are padded to 16 bytes by their owners)
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 256);
+  hipLaunchKernelGGL(k_upload16, dim3(grid), dim3(256), 0, s, (const uint4*)host_pinned, (uint4*)dev, n16, tick);
+  return hipGetLastError();
+}
+hipError_t phmm_results_by_kernel(const void* res, const double* out64, size_t n, void* stage_pinned, size_t off64_bytes, const unsigned long long* tick, hipStream_t s) {
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((2 * n + 255) / 256, 1), 128);
+  hipLaunchKernelGGL(k_phmm_results, dim3(grid), dim3(256), 0, s, (const uint32_t*)res, (const uint32_t*)out64, n, (uint32_t*)stage_pinned, off64_bytes / 4, tick);
+  return hipGetLastError();
+}
+}  // namespace accg
 
 extern "C" int accg_ctx_clock_ghz(accg_ctx* ctx, float* ghz) {
   if (!ctx) return ACCG_ERR_NOT_INITIALISED;
