@@ -67,6 +67,11 @@ struct accg_ctx {
   // a slot of an accg_phmm_ring: batch creation does not wait for its upload (the staging block is the slot's own and is not
   // touched again before the slot's results have been fetched)
   bool async_create = false;
+  // set for the duration of a blocking region call (accg_phmm_region, a mux leader's batch): the batch is created for ONE pass whose
+  // latency is what counts -- a batch small enough to leave most of the chip idle computes its fp64 values speculatively next to
+  // the fp32 sweep instead of behind it (phmm_host.cpp: run_spec)
+  bool oneshot = false;
+  bool alone = true;            // ... and no other caller is known to share the device right now (a mux tells: false while other lanes are busy)
   int wall_khz = 100000;        // rate of the device's constant wall clock (wall_clock64): 100 MHz on every gfx9
   // uploads and result blocks up to this size travel by copy kernels on the stream instead of hipMemcpyAsync (ACCG_COPY_KERNEL_MAX, bytes; 0 = never)
   size_t kernel_copy_max = 2u << 20;
@@ -91,6 +96,8 @@ struct SyncOnError {
   ~SyncOnError() { if (armed) (void)hipStreamSynchronize(s); }
 };
 // aux streams wait for everything queued on ctx->stream so far / ctx->stream waits for everything queued on the aux streams
+hipError_t ctx_need_aux(accg_ctx* c);         // the forked streams and their events exist from here on (made at first use)
+hipError_t ctx_need_tail(accg_ctx* c);
 hipError_t ctx_fork(accg_ctx* c);
 hipError_t ctx_fork_tail(accg_ctx* c);       // the same for the tail stream and its forked streams
 hipError_t ctx_join_tail(accg_ctx* c);
@@ -98,5 +105,6 @@ hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p);   // pinned staging o
 hipError_t ctx_join(accg_ctx* c);
 // transfers of a small batch as kernels on its stream (util_kernels.hip); host_pinned / stage_pinned: the context's staging block
 hipError_t upload_by_kernel(const void* host_pinned, void* dev, size_t bytes, unsigned long long* tick, hipStream_t s);
+hipError_t phmm_results_spec_by_kernel(const float* raw, const double* out64, size_t n, void* stage_pinned, size_t off64_bytes, const unsigned long long* tick, hipStream_t s);
 hipError_t phmm_results_by_kernel(const void* res, const double* out64, size_t n, void* stage_pinned, size_t off64_bytes, const unsigned long long* tick, hipStream_t s);
 }  // namespace accg

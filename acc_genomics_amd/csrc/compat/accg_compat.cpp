@@ -6,6 +6,7 @@
 #include <fstream>
 #include <sstream>
 #include <chrono>
+#include <mutex>
 #include <stdexcept>
 #include "../../../include/accg.h"
 
@@ -143,6 +144,23 @@ accg_ctx* ctx() {
   }
   return g_ctx;
 }
+// ... and one process-wide mux for the PairHMM entry points (include/accg.h: accg_phmm_mux): compute_fpga, every FalconPairHMM object
+// and every task instance put their region through it, so callers on several threads -- an accelerator manager runs several task
+// instances at a time -- share device batches instead of queueing small kernels behind each other.  ACCG_MUX_LANES (default 6) and
+// ACCG_MUX_MAX_REGIONS (default 64) size it.
+accg_phmm_mux* g_mux = nullptr;
+std::mutex g_mux_mu;
+}  // namespace
+accg_phmm_mux* accg_compat_mux() {
+  std::lock_guard<std::mutex> g(g_mux_mu);
+  if (!g_mux) {
+    const char* d = getenv("ACCG_DEVICE"); const char* l = getenv("ACCG_MUX_LANES"); const char* r = getenv("ACCG_MUX_MAX_REGIONS");
+    int st = accg_phmm_mux_create(d ? atoi(d) : 0, l && atoi(l) > 0 ? atoi(l) : 6, r && atoi(r) > 0 ? atoi(r) : 64, &g_mux);
+    if (st != ACCG_OK) throw std::runtime_error(std::string("accg_phmm_mux_create: ") + accg_strerror(st));
+  }
+  return g_mux;
+}
+namespace {
 bool is_capability_error(int st) { return st == ACCG_ERR_TOO_LONG || st == ACCG_ERR_BAD_BASE || st == ACCG_ERR_EMPTY_SEQ; }
 }  // namespace
 
@@ -157,8 +175,8 @@ float* compute_fpga(const char*, std::string read_data, std::string hap_data, ui
   if ((size_t)nr * nh > need) need = (size_t)nr * nh;
   if (need > g_ret_n) { free(g_ret); g_ret = (float*)aligned_alloc(4096, sizeof(float) * need); g_ret_n = need; }
   accg_counters c;
-  int st = accg_phmm_region(ctx(), read_data.data(), read_data.size(), hap_data.data(), hap_data.size(), ACCG_PHMM_FAST,
-                            g_ret, nullptr, &c);
+  int st = accg_phmm_mux_region(accg_compat_mux(), read_data.data(), read_data.size(), hap_data.data(), hap_data.size(), ACCG_PHMM_FAST,
+                                g_ret, nullptr, &c);
   if (is_capability_error(st)) return NULL;
   if (st != ACCG_OK) throw std::runtime_error(std::string("compute_fpga: ") + accg_strerror(st) + " " + accg_last_hip_error());
   if (c.kernel_ns) {
@@ -167,16 +185,19 @@ float* compute_fpga(const char*, std::string read_data, std::string hap_data, ui
   }
   return g_ret;
 }
-void cleanup() { ocl_release(); if (g_ctx) accg_shutdown(g_ctx); g_ctx = nullptr; free(g_ret); g_ret = nullptr; g_ret_n = 0; }
+void cleanup() {
+  ocl_release();
+  { std::lock_guard<std::mutex> g(g_mux_mu); if (g_mux) accg_phmm_mux_destroy(g_mux); g_mux = nullptr; }
+  if (g_ctx) accg_shutdown(g_ctx);
+  g_ctx = nullptr; free(g_ret); g_ret = nullptr; g_ret_n = 0;
+}
 
 // ---- FalconPairHMM ----------------------------------------------------------------------------------
-FalconPairHMM::FalconPairHMM() : ctx_(nullptr), kernel_ns_(0) {
-  const char* d = getenv("ACCG_DEVICE");
-  int st = accg_init(d ? atoi(d) : 0, &ctx_);
-  if (st != ACCG_OK) throw std::runtime_error(std::string("FalconPairHMM: ") + accg_strerror(st));
-}
+static FalconPairHMM_cpu_fn g_phmm_cpu_fallback = nullptr;
+void FalconPairHMM_set_cpu_fallback(FalconPairHMM_cpu_fn fn) { g_phmm_cpu_fallback = fn; }
+FalconPairHMM::FalconPairHMM() : mux_(accg_compat_mux()), kernel_ns_(0) {}     // (throws when there is no device, like the reference's constructor)
 FalconPairHMM::FalconPairHMM(char*) : FalconPairHMM() {}
-FalconPairHMM::~FalconPairHMM() { accg_shutdown(ctx_); }
+FalconPairHMM::~FalconPairHMM() {}
 double FalconPairHMM::get_kernel_time() { return kernel_ns_; }
 void FalconPairHMM::computePairhmm(pairhmmInput* in, pairhmmOutput* out, bool& usedFPGA) {
   std::vector<read_t> r(in->reads.size());
@@ -189,12 +210,15 @@ void FalconPairHMM::computePairhmm(pairhmmInput* in, pairhmmOutput* out, bool& u
   std::string rs = serialize(r.data(), (int)r.size()), hs = serialize(h.data(), (int)h.size());
   out->likelihoodData.assign(r.size() * h.size(), 0.0);
   accg_counters c;
-  int st = accg_phmm_region(ctx_, rs.data(), rs.size(), hs.data(), hs.size(), ACCG_PHMM_FAST, nullptr,
-                            out->likelihoodData.data(), &c);
+  int st = accg_phmm_mux_region(mux_, rs.data(), rs.size(), hs.data(), hs.size(), ACCG_PHMM_FAST, nullptr,
+                                out->likelihoodData.data(), &c);
   usedFPGA = (st == ACCG_OK);
   if (st == ACCG_OK) { kernel_ns_ += (double)c.kernel_ns; return; }
   out->likelihoodData.clear();
   if (!is_capability_error(st)) throw std::runtime_error(std::string("computePairhmm: ") + accg_strerror(st));
+  // FalconPairHMM.cpp:1184-1193: a region the accelerator cannot take goes to the host's own CPU code (computePairhmmAVX, :69-95) --
+  // the caller's, installed with FalconPairHMM_set_cpu_fallback; this library holds no CPU arithmetic
+  if (g_phmm_cpu_fallback) g_phmm_cpu_fallback(in, out);
 }
 
 // ---- per-pair PairHMM ------------------------------------------------------------------------------------
@@ -207,7 +231,7 @@ std::string one_hap(const testcase* tc) { hap_t h = {tc->haplen, (char*)tc->hap}
 float pair_f32(testcase* tc) {
   std::string rs = one_read(tc), hs = one_hap(tc);
   float raw = 0;
-  int st = accg_phmm_region(ctx(), rs.data(), rs.size(), hs.data(), hs.size(), ACCG_PHMM_FAST, &raw, nullptr, nullptr);
+  int st = accg_phmm_mux_region(accg_compat_mux(), rs.data(), rs.size(), hs.data(), hs.size(), ACCG_PHMM_FAST, &raw, nullptr, nullptr);
   if (st != ACCG_OK) throw std::runtime_error(std::string("compute_fp_avxs: ") + accg_strerror(st));
   return raw;
 }

@@ -57,6 +57,15 @@ typedef struct { std::string bases; } Hap;
 typedef struct { std::vector<Read> reads; std::vector<Hap> haps; } pairhmmInput;
 typedef struct { std::vector<double> likelihoodData; } pairhmmOutput;
 struct accg_ctx;
+struct accg_phmm_mux;
+// the process-wide mux the PairHMM entry points of this layer share (created at first use; cleanup() destroys it)
+accg_phmm_mux* accg_compat_mux();
+// The reference's computePairhmm falls back to its own CPU code (computePairhmmAVX, FalconPairHMM.cpp:69-95) for a region the
+// accelerator cannot take (:1184-1193).  This library holds no CPU arithmetic: a caller that wants that branch installs its CPU
+// function here; it is called with the same input and must fill output->likelihoodData.  Without one such a region comes back with
+// usedFPGA = false and an empty output.
+typedef void (*FalconPairHMM_cpu_fn)(pairhmmInput* input, pairhmmOutput* output);
+void FalconPairHMM_set_cpu_fallback(FalconPairHMM_cpu_fn fn);
 class FalconPairHMM {
  public:
   FalconPairHMM();
@@ -66,7 +75,7 @@ class FalconPairHMM {
   void computePairhmm(pairhmmInput* input, pairhmmOutput* output, bool& usedFPGA);
   double get_kernel_time();                  // accumulated device ns
  private:
-  accg_ctx* ctx_;
+  accg_phmm_mux* mux_;
   double kernel_ns_;
 };
 

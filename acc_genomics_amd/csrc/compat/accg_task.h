@@ -46,12 +46,11 @@ class PairHMM : public task_host::Task {
   virtual ~PairHMM();
   virtual uint64_t estimateClientTime() { return 0; }
   virtual uint64_t estimateTaskTime() { return 0; }
-  virtual void prepare();    // parse the wire blobs, upload (replaces deserialize + pack_fpga_input + clEnqueueMigrateMemObjects)
-  virtual void compute();    // run the kernels, fill output block 0 (replaces clEnqueueTask)
+  virtual void prepare();    // checks the input blocks (replaces deserialize + pack_fpga_input: the wire blobs are the device's input format)
+  virtual void compute();    // the region through the process-wide mux, output block 0 filled (replaces clEnqueueMigrateMemObjects + clEnqueueTask)
  private:
-  accg_ctx* ctx_;
-  accg_phmm_batch* batch_;
   uint64_t num_cell_;
+  bool prepared_;
 };
 
 extern "C" task_host::Task* create();

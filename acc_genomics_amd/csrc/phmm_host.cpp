@@ -10,6 +10,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -82,17 +83,8 @@ extern "C" int accg_init(int device, accg_ctx** out) {
   ACCG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   ACCG_HIP(hipEventCreate(&c->ev0));
   ACCG_HIP(hipEventCreate(&c->ev1));
-  for (int i = 0; i < accg_ctx::N_AUX; i++) {
-    ACCG_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
-    ACCG_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-  }
-  ACCG_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  ACCG_HIP(hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
-  for (int i = 0; i < accg_ctx::N_AUX; i++) {
-    ACCG_HIP(hipStreamCreateWithFlags(&c->aux_t[i], hipStreamNonBlocking));
-    ACCG_HIP(hipEventCreateWithFlags(&c->ev_join_t[i], hipEventDisableTiming));
-  }
-  ACCG_HIP(hipEventCreateWithFlags(&c->ev_fork_t, hipEventDisableTiming));
+  // (the forked streams and the tail stream are made when a batch first needs them -- ctx_need_aux / ctx_need_tail: a context that only
+  // ever sees regions one at a time runs on ONE stream, and sixteen such contexts do not crowd the device's few hardware queues)
   const HostTables& t = host_tables();
   const size_t nf = 128 * 3 + 8256, bytes = nf * sizeof(float) + nf * sizeof(double);
   ACCG_HIP(hipMalloc(&c->tab_mem, bytes));
@@ -214,8 +206,30 @@ hipError_t ctx_stage(accg_ctx* c, size_t bytes, void** p) {
   *p = c->h_stage;
   return hipSuccess;
 }
+hipError_t ctx_need_aux(accg_ctx* c) {
+  if (c->ev_fork) return hipSuccess;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) {
+    e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  return e;
+}
+hipError_t ctx_need_tail(accg_ctx* c) {
+  if (c->ev_fork_t) return hipSuccess;
+  hipError_t e = hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking);
+  for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) {
+    e = hipStreamCreateWithFlags(&c->aux_t[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join_t[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork_t, hipEventDisableTiming);
+  return e;
+}
 hipError_t ctx_fork(accg_ctx* c) {
-  hipError_t e = hipEventRecord(c->ev_fork, c->stream);
+  hipError_t e = ctx_need_aux(c);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(c->ev_fork, c->stream);
   for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) e = hipStreamWaitEvent(c->aux[i], c->ev_fork, 0);
   return e;
 }
@@ -228,7 +242,9 @@ hipError_t ctx_join(accg_ctx* c) {
   return e;
 }
 hipError_t ctx_fork_tail(accg_ctx* c) {
-  hipError_t e = hipEventRecord(c->ev_fork_t, c->tail);
+  hipError_t e = ctx_need_tail(c);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(c->ev_fork_t, c->tail);
   for (int i = 0; i < accg_ctx::N_AUX && e == hipSuccess; i++) e = hipStreamWaitEvent(c->aux_t[i], c->ev_fork_t, 0);
   return e;
 }
@@ -385,6 +401,14 @@ struct accg_phmm_batch {
   // One pass = memset + a launch per (lanes, K) class on forked streams + rescue plan + the rescue classes and their strict
   // re-runs: captured once per arithmetic mode into a graph and replayed (every argument is fixed at batch creation).
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  // Speculative fp64 pass (one-shot batches that leave most of the chip idle, fast mode): jobs for EVERY read, made on the host with the
+  // planner's grouping rule, run next to the fp32 sweep on a forked stream; the results kernel then counts what was needed (run_spec)
+  bool spec = false, spec_ran = false;                    // spec_ran: the last pass was a speculative one (its results are fetched accordingly)
+  std::vector<PhmmWork> spec_jobs;                        // the classes' job arrays back to back, class c at [spec_off[c], spec_off[c + 1])
+  uint32_t spec_off[PHMM_RESCUE_CLASSES + 1] = {0};
+  std::vector<uint32_t> spec_counts;                      // PHMM_RESCUE_CLASSES words, uploaded (what the planner's counters would hold)
+  DevBuf<PhmmWork> d_spec_jobs;
+  DevBuf<uint32_t> d_spec_counts;
   bool kernel_copies = false;    // a small batch: upload and results travel by copy kernels on the stream (accg_ctx::kernel_copy_max)
   bool results_late = false;     // ring: the downloads are queued by results_finish, not behind the kernels
   bool results_fetched = false;  // the raw results (and, for kernel copies, the fp64 values) of the last pass are in the staging block
@@ -453,7 +477,7 @@ int parse_reads(const uint8_t* p, size_t bytes, uint32_t base_off, std::vector<S
   // (inside the per-region parallel loop of a multi-region batch this stays serial: no nested teams)
   form.resize(first + (size_t)n);
   int bad = 0, dp = 0;
-#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) reduction(| : bad, dp) if (n >= 512)
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) reduction(| : bad, dp) if (n >= 512 && accg::host_threads() > 1)
   for (int i = 0; i < n; i++) {
     const SeqRef& r = refs[first + (size_t)i];
     const uint8_t* q = p + (r.off - base_off);
@@ -555,13 +579,19 @@ void partition(accg_phmm_batch& b) {
   const int min_form = (e6 && e6[0] == '0') ? 7 : ef ? std::max(5, std::min(7, atoi(ef))) : 5;
   auto form_of = [&](uint32_t rid) { return std::max((int)b.rd_form[rid], min_form); };
   const char* e8 = getenv("ACCG_PHMM_LPP8");                 // A/B knob: largest K run with 8 lanes per read (0 = never)
-  const int max_k8 = e8 ? atoi(e8) : PHMM_K8_DEFAULT;
+  // A one-shot batch of a region or two leaves most SIMDs idle and every wavefront runs at its own issue cadence: what counts is the
+  // length of a job, and sixteen lanes per read halve the rows per lane (a configs[3] region: sweep 41 -> 30 us).  "Small": even with
+  // twice the wavefronts there is at most one per SIMD (reads / 4 wavefronts per haplotype).
+  uint64_t jobs16 = 0;
+  for (const Region& r : b.regions) jobs16 += (uint64_t)((r.n_reads + 3) / 4) * r.n_haps;
+  const bool latency_shapes = b.ctx->oneshot && jobs16 <= 4ull * (uint64_t)std::max(b.ctx->n_cu, 1);
+  const int max_k8 = e8 ? atoi(e8) : latency_shapes ? 0 : PHMM_K8_DEFAULT;
   std::vector<std::vector<Group>> groups(b.regions.size());
   b.sorted_reads.assign(b.rd.size(), 0);
   b.regions_dev.assign(b.regions.size(), PhmmRegionDev{0, 0, 0, 0, 0, 0});
   uint64_t kw[4][PHMM_MAX_K + 1] = {{0}};     // haplotype passes per (lanes per read: 8, 16, 32, 64; K)
   uint64_t n_form5 = 0, n_other = 0;          // ... in the five-operation form (whose jobs may go in pairs) / in the others
-#pragma omp parallel for schedule(dynamic, 4) num_threads(accg::host_threads()) if (b.regions.size() >= 32)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(accg::host_threads()) if (b.regions.size() >= 32 && accg::host_threads() > 1)
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     const Region& r = b.regions[ri];
     if (r.n_reads == 0 || r.n_haps == 0) continue;
@@ -724,9 +754,17 @@ void partition(accg_phmm_batch& b) {
     ev.span = span;
     return ev;
   };
+  // One haplotype per job and every job on a SIMD of its own: nothing to search (the makespan is the longest job, and longer runs
+  // only lengthen it).  The blocking call per region lands here.
+  {
+    uint64_t jobs1 = 0;
+    for (size_t ri = 0; ri < b.regions.size(); ri++) jobs1 += (uint64_t)groups[ri].size() * b.regions[ri].n_haps;
+    if (jobs1 <= 4ull * (uint64_t)n_cu && !getenv("ACCG_PHMM_STREAM_BUDGET")) { cand.clear(); cand.push_back(1); }
+  }
   std::vector<double> span1(cand.size(), -1.0), span2(cand.size(), -1.0);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (cand.size() * b.regions.size() >= 512)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (cand.size() * b.regions.size() >= 512 && accg::host_threads() > 1)
   for (int ci = 0; ci < (int)cand.size(); ci++) {
+    if (cand.size() == 1) { span1[ci] = 0.0; continue; }      // a single candidate is taken as it is
     const Eval e1 = evaluate(cand[ci], false);
     span1[ci] = e1.span;
     if (dom5 && e1.pays) span2[ci] = evaluate(cand[ci], true).span;
@@ -786,7 +824,7 @@ void partition(accg_phmm_batch& b) {
     }
     jobs.resize(job0);
   }
-#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (b.regions.size() >= 8)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (b.regions.size() >= 8 && accg::host_threads() > 1)
   for (size_t ri = 0; ri < b.regions.size(); ri++) {
     if (groups[ri].empty()) continue;
     const Region& r = b.regions[ri];
@@ -946,8 +984,9 @@ PhmmArgs<T> make_args(const accg_phmm_batch& b, T* out, const PhmmTables<T>& tab
   return a;
 }
 
-int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
+int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, bool no_flags = false) {
   PhmmArgs<float> a = make_args<float>(*b, b->d_out.p, b->ctx->tab_f);
+  if (no_flags) a.read_flag = nullptr;            // a speculative pass: no planner will read (and clear) them
   // A pass needs no memset: the read flags are cleared by the planner as it reads them, the rescue job counts and the counter of
   // rescued pairs by block 0 of every sweep launch (the previous pass is through with them, this pass's planner runs behind the sweep),
   // and batch creation left all of them at zero.  ACCG_PHMM_PREPARE_EACH_PASS=1: the per-row records of the five-operation sweep
@@ -1083,9 +1122,24 @@ int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
 
 }  // namespace
 
+// One region's wire blobs, parsed and validated (lengths, bases, the range tests of the sweep's forms); offsets are relative to the
+// region's own blobs.  Regions are independent: a multi-region batch parses them on the host's threads, the callers of an
+// accg_phmm_mux each parse their own before they queue up.
+struct PhmmParsed { std::vector<SeqRef> rd, hp; std::vector<uint8_t> form; std::vector<const uint8_t*> hp_ptr; bool has_n = false, deep = false; int nr = 0, nh = 0; };
+static void parse_region(const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes, PhmmParsed& P) {
+  P.nr = parse_reads((const uint8_t*)reads_ser, reads_bytes, 0u, P.rd, P.form, P.deep);
+  if (P.nr >= 0) P.nh = parse_haps((const uint8_t*)haps_ser, haps_bytes, 0u, P.hp, P.has_n, P.hp_ptr);
+}
+static int phmm_batch_create_impl(accg_ctx* ctx, int n_regions, const void* const* reads_ser, const size_t* reads_bytes, const void* const* haps_ser,
+                                  const size_t* haps_bytes, const PhmmParsed* const* pre, accg_phmm_batch** out);
 extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* const* reads_ser,
                                       const size_t* reads_bytes, const void* const* haps_ser,
                                       const size_t* haps_bytes, accg_phmm_batch** out) {
+  return phmm_batch_create_impl(ctx, n_regions, reads_ser, reads_bytes, haps_ser, haps_bytes, nullptr, out);
+}
+// pre (nullable): the regions already parsed (by parse_region over the same blobs)
+static int phmm_batch_create_impl(accg_ctx* ctx, int n_regions, const void* const* reads_ser, const size_t* reads_bytes, const void* const* haps_ser,
+                                  const size_t* haps_bytes, const PhmmParsed* const* pre, accg_phmm_batch** out) {
   if (!ctx) return ACCG_ERR_NOT_INITIALISED;
   if (!out || n_regions < 0 || (n_regions > 0 && (!reads_ser || !reads_bytes || !haps_ser || !haps_bytes))) return ACCG_ERR_BAD_ARG;
   *out = nullptr;
@@ -1100,26 +1154,26 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   if (roff >= (1ull << 32) || hoff >= (1ull << 32)) return ACCG_ERR_TOO_LONG;   // 32-bit blob offsets
   // Regions are parsed (lengths, base validation, the range tests of the sweep's forms) independently of each other, on the host
   // threads this process may use when there are enough of them, and merged in order.
-  struct Parsed { std::vector<SeqRef> rd, hp; std::vector<uint8_t> form; std::vector<const uint8_t*> hp_ptr; bool has_n = false, deep = false; int nr = 0, nh = 0; };
-  std::vector<Parsed> parsed((size_t)n_regions);
+  std::vector<PhmmParsed> parsed(pre ? (size_t)0 : (size_t)n_regions);
   std::vector<uint64_t> roffs((size_t)n_regions + 1, 0), hoffs((size_t)n_regions + 1, 0);
   for (int i = 0; i < n_regions; i++) { roffs[i + 1] = roffs[i] + reads_bytes[i]; hoffs[i + 1] = hoffs[i] + haps_bytes[i]; }
-#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (n_regions >= 8)
-  for (int i = 0; i < n_regions; i++) {
-    Parsed& P = parsed[i];
-    P.nr = parse_reads((const uint8_t*)reads_ser[i], reads_bytes[i], (uint32_t)roffs[i], P.rd, P.form, P.deep);
-    if (P.nr >= 0) P.nh = parse_haps((const uint8_t*)haps_ser[i], haps_bytes[i], (uint32_t)hoffs[i], P.hp, P.has_n, P.hp_ptr);
+  if (!pre) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (n_regions >= 8 && accg::host_threads() > 1)
+    for (int i = 0; i < n_regions; i++) parse_region(reads_ser[i], reads_bytes[i], haps_ser[i], haps_bytes[i], parsed[i]);
   }
   for (int i = 0; i < n_regions; i++) {
-    const Parsed& P = parsed[i];
+    const PhmmParsed& P = pre ? *pre[i] : parsed[i];
     if (P.nr < 0) return P.nr;
     if (P.nh < 0) return P.nh;
     Region r;
     r.read0 = (uint32_t)b->rd.size(); r.hap0 = (uint32_t)b->hp.size(); r.out0 = b->pairs;
     const int nr = P.nr, nh = P.nh;
-    b->rd.insert(b->rd.end(), P.rd.begin(), P.rd.end()); b->rd_form.insert(b->rd_form.end(), P.form.begin(), P.form.end());
+    // (a parsed region's offsets are relative to its own blobs: shifted to the blobs' places in the batch)
+    for (const SeqRef& x : P.rd) b->rd.push_back({x.off + (uint32_t)roffs[i], x.len});
+    b->rd_form.insert(b->rd_form.end(), P.form.begin(), P.form.end());
     for (uint8_t f : P.form) b->all_form5 &= f == 5;
-    b->hp.insert(b->hp.end(), P.hp.begin(), P.hp.end()); b->hp_ptr.insert(b->hp_ptr.end(), P.hp_ptr.begin(), P.hp_ptr.end());
+    for (const SeqRef& x : P.hp) b->hp.push_back({x.off + (uint32_t)hoffs[i], x.len});
+    b->hp_ptr.insert(b->hp_ptr.end(), P.hp_ptr.begin(), P.hp_ptr.end());
     b->has_n |= P.has_n;
     b->redo_possible |= P.deep;
     r.n_reads = (uint32_t)nr; r.n_haps = (uint32_t)nh;
@@ -1144,6 +1198,53 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const auto tp0 = std::chrono::steady_clock::now();
   partition(*b);
   const auto tp1 = std::chrono::steady_clock::now();
+  // Speculative fp64 jobs: only for a one-shot batch (accg_ctx::oneshot) whose fp32 jobs and fp64 jobs TOGETHER leave every wavefront a
+  // SIMD of its own, whose reads all pass the five-operation form's range tests (the merged rescue windows), none in a class outside
+  // them, and none that could need the strict re-run launch.  ACCG_PHMM_SPEC=0 turns it off.
+  {
+    static const bool spec_off_env = [] { const char* e = getenv("ACCG_PHMM_SPEC"); return e && e[0] == '0'; }();
+    bool ok = ctx->oneshot && ctx->alone && !spec_off_env && b->all_form5 && !b->redo_possible && !b->rd.empty();
+    uint64_t n_items[PHMM_RESCUE_CLASSES] = {0};
+    if (ok) {
+      for (size_t ri = 0; ri < b->regions.size() && ok; ri++) {
+        const Region& r = b->regions[ri];
+        const uint32_t n_chunks = b->regions_dev[ri].n_chunks;
+        for (uint32_t i = 0; i < r.n_reads;) {
+          int cls, lpp, K;
+          phmm_rescue_class(b->rd[b->sorted_reads[r.read0 + i]].len, &cls, &lpp, &K);      // the longest read of a group decides its class (phmm_rescue_plan)
+          if (phmm_rescue_window(cls) < 0) { ok = false; break; }
+          n_items[cls] += n_chunks;
+          i += 64u / (uint32_t)lpp;
+        }
+      }
+      uint64_t total = 0;
+      for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) total += n_items[c];
+      ok = ok && total > 0 && total + b->work.size() <= 4ull * (uint64_t)std::max(ctx->n_cu, 1);
+    }
+    if (ok) {
+      for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b->spec_off[c + 1] = b->spec_off[c] + (uint32_t)n_items[c];
+      b->spec_jobs.assign(b->spec_off[PHMM_RESCUE_CLASSES], PhmmWork{});
+      b->spec_counts.assign(PHMM_RESCUE_CLASSES, 0u);
+      for (size_t ri = 0; ri < b->regions.size(); ri++) {
+        const Region& r = b->regions[ri];
+        const PhmmRegionDev& rdv = b->regions_dev[ri];
+        for (uint32_t i = 0; i < r.n_reads;) {
+          int cls, lpp, K;
+          phmm_rescue_class(b->rd[b->sorted_reads[r.read0 + i]].len, &cls, &lpp, &K);
+          const uint32_t per = 64u / (uint32_t)lpp;
+          PhmmWork w;
+          for (uint32_t g = 0; g < PHMM_GROUPS; g++) w.read[g] = (g < per && i + g < r.n_reads) ? b->sorted_reads[r.read0 + i + g] : PHMM_NO_READ;
+          w.pad_[0] = w.pad_[1] = 0;
+          for (uint32_t c = 0; c < rdv.n_chunks; c++) {
+            w.hap_off = b->chunks_dev[rdv.chunk0 + c].ids0; w.n_haps = b->chunks_dev[rdv.chunk0 + c].n;
+            b->spec_jobs[b->spec_off[cls] + b->spec_counts[cls]++] = w;
+          }
+          i += per;
+        }
+      }
+      b->spec = true;
+    }
+  }
   hipStream_t s = ctx->stream;
   int st;
   for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) {
@@ -1159,7 +1260,8 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   const size_t o_rblob = take(roff + 16), o_hblob = take(hoff + 16), o_rd = take(vbytes(b->rd)), o_hp = take(vbytes(b->hp)),
                o_rd_out = take(vbytes(b->rd_out)), o_hp_local = take(vbytes(b->hp_local)), o_hap_ids = take(b->hap_ids.size() * sizeof(PhmmHapDesc)),
                o_work = take(vbytes(b->work)), o_regions = take(vbytes(b->regions_dev)), o_chunks = take(vbytes(b->chunks_dev)),
-               o_sorted = take(vbytes(b->sorted_reads)), o_row0 = take(vbytes(b->rd_row0)), o_shape = take(vbytes(b->rd_shape)), o_streams = take(b->streams.size() + 16);
+               o_sorted = take(vbytes(b->sorted_reads)), o_row0 = take(vbytes(b->rd_row0)), o_shape = take(vbytes(b->rd_shape)), o_streams = take(b->streams.size() + 16),
+               o_spec_jobs = take(vbytes(b->spec_jobs)), o_spec_counts = take(vbytes(b->spec_counts));
   const size_t upload_bytes = off;
   if (b->n_rows >= (1ull << 32)) return ACCG_ERR_TOO_LONG;
   const size_t n_rec = (size_t)b->n_rows + 1;
@@ -1182,6 +1284,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   b->d_regions.place(base, o_regions, b->regions_dev.size()); b->d_chunks.place(base, o_chunks, b->chunks_dev.size());
   b->d_sorted_reads.place(base, o_sorted, b->sorted_reads.size());
   b->d_rd_row0.place(base, o_row0, b->rd_row0.size()); b->d_rd_shape.place(base, o_shape, b->rd_shape.size()); b->d_streams.place(base, o_streams, b->streams.size() + 16);
+  b->d_spec_jobs.place(base, o_spec_jobs, b->spec_jobs.size()); b->d_spec_counts.place(base, o_spec_counts, b->spec_counts.size());
   b->d_rec_coef.place(base, o_rec_coef, n_rec); b->d_rec_dist.place(base, o_rec_dist, n_rec); b->d_rec_misc.place(base, o_rec_misc, n_rec);
   b->d_clock.place(base, o_clock, 4);
   b->d_flagged.place(base, o_flagged, b->rd.size() + 1);
@@ -1208,7 +1311,7 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
   ACCG_HIP(ctx_stage(ctx, upload_bytes + 16, &stage_v));
   const auto tq2 = std::chrono::steady_clock::now();
   uint8_t* stage = (uint8_t*)stage_v;
-#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n_regions >= 32)
+#pragma omp parallel for schedule(static) num_threads(accg::host_threads()) if (n_regions >= 32 && accg::host_threads() > 1)
   for (int i = 0; i < n_regions; i++) {
     if (reads_bytes[i]) memcpy(stage + o_rblob + roffs[i], reads_ser[i], reads_bytes[i]);
     if (haps_bytes[i]) memcpy(stage + o_hblob + hoffs[i], haps_ser[i], haps_bytes[i]);
@@ -1222,20 +1325,33 @@ extern "C" int accg_phmm_batch_create(accg_ctx* ctx, int n_regions, const void* 
     for (size_t i = 0; i < b->hap_ids.size(); i++) { const uint32_t g = b->hap_ids[i]; hd[i] = PhmmHapDesc{b->hp[g].off, b->hp[g].len, b->hp_local[g], g}; }
   }
   put(o_work, b->work); put(o_regions, b->regions_dev); put(o_chunks, b->chunks_dev); put(o_sorted, b->sorted_reads);
-  put(o_row0, b->rd_row0); put(o_shape, b->rd_shape); put(o_streams, b->streams);
+  put(o_row0, b->rd_row0); put(o_shape, b->rd_shape); put(o_streams, b->streams); put(o_spec_jobs, b->spec_jobs); put(o_spec_counts, b->spec_counts);
   memset(stage + o_streams + b->streams.size(), 0, 16);
   b->hp_ptr.clear(); b->hp_ptr.shrink_to_fit();            // the caller's blobs are not ours beyond this call
   const auto tq3 = std::chrono::steady_clock::now();
   // a small batch goes over by a copy kernel on its stream (no DMA engine in the chain: util_kernels.hip), which also notes the device's
   // wall clock at the start of the batch's device work (accg_phmm_region reports the device time from it)
   b->kernel_copies = upload_bytes + 16 <= ctx->kernel_copy_max && results_stage_bytes(b->pairs) <= ctx->kernel_copy_max;
+  b->spec = b->spec && b->kernel_copies;
   if (upload_bytes && b->kernel_copies) ACCG_HIP(upload_by_kernel(stage, base, upload_bytes, reinterpret_cast<unsigned long long*>(b->d_clock.p) + 2, s));
   else if (upload_bytes) ACCG_HIP(hipMemcpyAsync(base, stage, upload_bytes, hipMemcpyHostToDevice, s));
   const auto tq4 = std::chrono::steady_clock::now();
   // out64, state, out start at zero: cleared by the kernel that writes the per-row records of the five-operation sweep (phmm_dev.h:
   // PhmmRowRecs, from the uploaded reads) when there is one -- a hipMemsetAsync of a megabyte or two costs the host 100 to 150 us
   const size_t clear_bytes = (o_out - o_out64) + (b->pairs + 1) * sizeof(float);       // (o_out64 is 256-byte aligned, sizes are multiples of 4)
-  if (b->any_form5 && b->n_rows && clear_bytes / 4 < (1ull << 32)) {
+  b->spec = b->spec && b->any_form5 && b->n_rows;
+  if (b->spec) {
+    // A speculative batch (run_spec): the fp32 half -- row records, then the sweep -- goes onto a side stream behind the upload, the
+    // fp64 kernels take the main stream right behind the upload.  The fp64 values of every pair get written, so only the state words
+    // and the fp32 results are cleared here (the fp64 kernels may be writing theirs at the same time).
+    ACCG_HIP(ctx_need_aux(ctx));
+    hipStream_t side = ctx->aux[accg_ctx::N_AUX - 1];
+    ACCG_HIP(hipEventRecord(ctx->ev_fork, s));
+    ACCG_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
+    const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, ctx->tab_f);
+    ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), reinterpret_cast<uint32_t*>(base + o_state), (uint32_t)((clear_bytes - (o_state - o_out64)) / 4), side));
+    ACCG_HIP(hipEventRecord(ctx->ev_join[accg_ctx::N_AUX - 1], side));      // (for a pass that is NOT speculative, e.g. strict mode: run_direct waits for it)
+  } else if (b->any_form5 && b->n_rows && clear_bytes / 4 < (1ull << 32)) {
     const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, ctx->tab_f);
     ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), reinterpret_cast<uint32_t*>(base + o_out64), (uint32_t)(clear_bytes / 4), s));
   } else {
@@ -1297,13 +1413,54 @@ int join_tail(accg_phmm_batch* b) {
   if (b->tail_pending) { ACCG_HIP(hipStreamWaitEvent(b->ctx->stream, b->tail_done, 0)); b->tail_pending = false; }
   return ACCG_OK;
 }
+// A one-shot batch small enough to leave most of the chip idle (accg_phmm_batch::spec): the fp64 values of EVERY pair are computed
+// next to the fp32 sweep, on a forked stream, by the merged rescue kernels over jobs the host made at creation -- no planner, no
+// fp64 launch behind the sweep.  A region of 2048 pairs: sweep 48 us + planner 7 + rescue 49 one behind the other become ~50 us side by
+// side.  The values a caller gets are the same: a pair's fp64 result does not depend on which reads share its wavefront, and the
+// results kernel picks (and counts) the pairs below MIN_ACCEPTED exactly as the rescue would have.
+int run_spec(accg_phmm_batch* b) {
+  accg_ctx* c = b->ctx;
+  hipStream_t side = c->aux[accg_ctx::N_AUX - 1];            // (made at creation, where the row records were queued on it behind the upload)
+  // the fp64 kernels: main stream, right behind the upload -- they are the longer half (sixteen lanes x K of 5 to 8 in fp64 against the
+  // sweep's eight lanes x K up to 13 in fp32) and start without a cross-queue dependency
+  PhmmArgs<double> a = make_args<double>(*b, b->d_out64.p, c->tab_d);
+  a.work = b->d_spec_jobs.p; a.raw = nullptr; a.n_rescued = nullptr;
+  a.stream_cap = b->rescue_stream_cap; a.haps_cap = b->rescue_haps_cap;
+  a.job_count = nullptr; a.job_map = nullptr; a.is_redo = 0; a.redo_count = nullptr; a.redo_list = nullptr;
+  PhmmRescueSet rs;
+  for (int k = 0; k <= PHMM_RESCUE_CLASSES; k++) rs.off[k] = b->spec_off[k];
+  rs.counts = b->d_spec_counts.p;
+  for (int w = 0; w < 2; w++) {
+    uint64_t units = 0; size_t lds = 0;
+    for (int k = 0; k < PHMM_RESCUE_CLASSES; k++) {
+      if (!b->spec_counts[(size_t)k] || phmm_rescue_window(k) != w) continue;
+      int lpp_c, k_c;
+      phmm_rescue_shape(k, &lpp_c, &k_c);
+      units += b->spec_counts[(size_t)k];
+      lds = std::max(lds, phmm_lds_bytes(k_c, 8, a.nchar, a.stream_cap, a.haps_cap, lpp_c, true, false, 1));
+    }
+    if (units) ACCG_HIP(phmm_launch_rescue_multi(w, 1, lds, a, rs, (uint32_t)units, c->stream));
+  }
+  // the fp32 sweep: side stream, behind the row records (launch_f32 queues on the context's stream: the side stream plays it for the call)
+  std::swap(c->stream, side);
+  const int st = launch_f32(b, ACCG_PHMM_FAST, nullptr, nullptr, true);
+  std::swap(c->stream, side);
+  if (st != ACCG_OK) return st;
+  ACCG_HIP(hipEventRecord(c->ev_join[accg_ctx::N_AUX - 1], side));
+  ACCG_HIP(hipStreamWaitEvent(c->stream, c->ev_join[accg_ctx::N_AUX - 1], 0));
+  return ACCG_OK;
+}
 int run_direct(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
   int st;
+  if (b->spec && mode == ACCG_PHMM_FAST && !ev_begin) { b->spec_ran = true; return run_spec(b); }
+  b->spec_ran = false;
+  if (b->spec) ACCG_HIP(hipStreamWaitEvent(b->ctx->stream, b->ctx->ev_join[accg_ctx::N_AUX - 1], 0));     // the side stream's row records and clears
   if (!pipeline_on()) {
     if ((st = launch_f32(b, mode, ev_begin, ev_end)) != ACCG_OK) return st;
     return launch_rescue(b, mode);
   }
   accg_ctx* c = b->ctx;
+  ACCG_HIP(ctx_need_tail(c));
   if (b->runs >= 1) {
     if ((st = ensure_alt(b)) != ACCG_OK) return st;
     swap_sets(b);
@@ -1457,7 +1614,9 @@ namespace {
 // results of a pass in two halves for the ring: the device-to-host copies queued behind the kernels (both result arrays, always),
 // and the host half -- wait, log10 (same libm as the reference) -- when the caller comes for them
 // Where one region's share of a pass's results goes (a batch's results are concatenated in region order)
-struct ResultDst { float* raw; double* l10; accg_counters* cnt; uint64_t pairs, cells; };
+// (r64: nullable; the fp64 values of the region's pairs for a caller that takes the log10 itself -- filled only when the pass rescued
+// something, *resc = the region's rescued pairs)
+struct ResultDst { float* raw; double* l10; accg_counters* cnt; uint64_t pairs, cells; double* r64 = nullptr; uint64_t* resc = nullptr; };
 // The downloads of a ticket: queued behind its kernels at once (plain ring: one caller thread, nothing else submits meanwhile), or
 // -- threaded ring, `late` -- only when the kernels have finished: a copy that sits in a DMA queue waiting for a kernel blocks the
 // NEXT copy submitted to that queue, another slot's upload, inside hipMemcpyAsync on that slot's worker (measured: creations of
@@ -1471,7 +1630,8 @@ int results_enqueue(accg_phmm_batch* b, bool late) {
   uint8_t* stage = (uint8_t*)stage_v;
   if (b->kernel_copies) {
     b->results_late = false; b->results_fetched = true;
-    ACCG_HIP(phmm_results_by_kernel(b->res_ptr, b->d_out64.p, n, stage, off64, reinterpret_cast<unsigned long long*>(b->d_clock.p) + 2, b->ctx->stream));
+    if (b->spec_ran) ACCG_HIP(phmm_results_spec_by_kernel(b->d_out.p, b->d_out64.p, n, stage, off64, reinterpret_cast<unsigned long long*>(b->d_clock.p) + 2, b->ctx->stream));
+    else ACCG_HIP(phmm_results_by_kernel(b->res_ptr, b->d_out64.p, n, stage, off64, reinterpret_cast<unsigned long long*>(b->d_clock.p) + 2, b->ctx->stream));
     return ACCG_OK;
   }
   b->results_late = late; b->results_fetched = false;
@@ -1500,7 +1660,7 @@ int results_finish(accg_phmm_batch* b, const ResultDst* dst, size_t n_dst) {
   const float* raw = (const float*)(stage + RES_HDR);
   const double* r64 = (const double*)(stage + off64);
   bool want_l10 = false;
-  for (size_t d = 0; d < n_dst; d++) want_l10 |= dst[d].l10 != nullptr;
+  for (size_t d = 0; d < n_dst; d++) want_l10 |= dst[d].l10 != nullptr || dst[d].r64 != nullptr;
   if (want_l10 && n && nresc && !b->results_fetched) {              // the fp64 values only when something was rescued
     ACCG_HIP(hipMemcpyAsync(stage + off64, b->d_out64.p, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
     ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
@@ -1520,11 +1680,11 @@ int results_finish(accg_phmm_batch* b, const ResultDst* dst, size_t n_dst) {
       for (size_t i = 0; i < m; i++)
         out_log10[i] = rw[i] < PHMM_MIN_ACCEPTED ? log10(rd[i]) - t.log10_init_d : (double)(log10f(rw[i]) - t.log10_init_f);
     }
-    if (D.cnt) {
-      uint64_t resc = nresc;
-      if (n_dst > 1) { resc = 0; for (size_t i = 0; i < m; i++) resc += raw[o + i] < PHMM_MIN_ACCEPTED; }      // this region's share
-      D.cnt->cells = D.cells; D.cnt->pairs = m; D.cnt->kernel_ns = b->last_kernel_ns; D.cnt->rescued = resc;
-    }
+    uint64_t resc = nresc;
+    if (n_dst > 1 && (D.cnt || D.resc)) { resc = 0; for (size_t i = 0; i < m; i++) resc += raw[o + i] < PHMM_MIN_ACCEPTED; }      // this region's share
+    if (D.r64 && m && nresc) memcpy(D.r64, r64 + o, m * sizeof(double));
+    if (D.resc) *D.resc = resc;
+    if (D.cnt) { D.cnt->cells = D.cells; D.cnt->pairs = m; D.cnt->kernel_ns = b->last_kernel_ns; D.cnt->rescued = resc; }
     o += m;
   }
   return ACCG_OK;
@@ -1597,7 +1757,8 @@ int peek_regions(int n_regions, const void* const* reads_ser, const size_t* read
 // One blocking pass over regions handed over together: create (no wait for the upload: the staging block is sized up front and not
 // touched again before the results are in), run, results -- ONE wait for the device in the whole call.
 int region_call(accg_ctx* ctx, int n_regions, const void* const* rs, const size_t* rb, const void* const* hs, const size_t* hb, int mode,
-                const ResultDst* dst_in, size_t n_dst, float* out_raw, double* out_log10, accg_counters* cnt) {
+                ResultDst* dst_in, size_t n_dst, float* out_raw, double* out_log10, accg_counters* cnt, const PhmmParsed* const* pre = nullptr,
+                bool alone = true) {
   static const bool trace = getenv("ACCG_TRACE") != nullptr;     // stage timings of the one-shot path on stderr
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
@@ -1610,9 +1771,9 @@ int region_call(accg_ctx* ctx, int n_regions, const void* const* rs, const size_
   ACCG_HIP(ctx_stage(ctx, std::max(results_stage_bytes(pairs), 3 * blob + ((size_t)1 << 20)), &stage));
   accg_phmm_batch* b = nullptr;
   const bool was_async = ctx->async_create;
-  ctx->async_create = true;
-  st = accg_phmm_batch_create(ctx, n_regions, rs, rb, hs, hb, &b);
-  ctx->async_create = was_async;
+  ctx->async_create = true; ctx->oneshot = true; ctx->alone = alone;
+  st = phmm_batch_create_impl(ctx, n_regions, rs, rb, hs, hb, pre, &b);
+  ctx->async_create = was_async; ctx->oneshot = false;
   if (st != ACCG_OK) return st;
   const auto t1 = clk::now();
   const bool events = !b->kernel_copies;           // a small batch times itself on the device's wall clock (results_finish)
@@ -1630,6 +1791,15 @@ int region_call(accg_ctx* ctx, int n_regions, const void* const* rs, const size_
     }
     ResultDst one{out_raw, out_log10, cnt, b->pairs, b->cells};
     if (!dst_in) { dst_in = &one; n_dst = 1; }
+    else if (n_dst == b->regions.size()) {          // one destination per region: its pairs and cells
+      for (size_t d = 0; d < n_dst; d++) {
+        const Region& r = b->regions[d];
+        uint64_t rsum = 0, hsum = 0;
+        for (uint32_t k = 0; k < r.n_reads; k++) rsum += b->rd[r.read0 + k].len;
+        for (uint32_t k = 0; k < r.n_haps; k++) hsum += b->hp[r.hap0 + k].len;
+        dst_in[d].pairs = (uint64_t)r.n_reads * r.n_haps; dst_in[d].cells = rsum * hsum;
+      }
+    }
     if (trace) { hipStreamSynchronize(ctx->stream); t2 = clk::now(); }
     st = results_finish(b, dst_in, n_dst);
     t3 = clk::now();
@@ -1861,4 +2031,151 @@ extern "C" void accg_phmm_ring_destroy(accg_phmm_ring* r) {
   for (accg_phmm_batch* b : r->batch) if (b) accg_phmm_batch_destroy(b);
   for (accg_ctx* c : r->ctx) accg_shutdown(c);
   delete r;
+}
+
+// ---- regions from concurrent blocking callers -------------------------------------------------------------------------------------
+// The reference's callers hand over ONE region per blocking call (compute_fpga, pairhmm/host/PairHMMFpga.cpp:125-162;
+// FalconPairHMM::computePairhmm, pairhmm/xlnx/host/FalconPairHMM.cpp:1184-1193) and an accelerator manager runs one PairHMM task per
+// request, several at a time (pairhmm/task/xlnx/PairHMMTask.cpp:27-143).  One region is 256 wavefront jobs: a twentieth of the chip for
+// some 100 us, and the device runs the kernels of different streams one or two at a time (rocprofv3 --kernel-trace of sixteen caller
+// threads with a context each: two hardware queues busy, never more than two kernels at once).  So concurrent callers are COMBINED: a
+// caller parses its own region, queues it, and -- if one of the mux's few contexts ("lanes") is free -- becomes the leader of everything
+// queued so far: one device batch (merged launches, one upload, one results block), whose results it hands back to the callers it took
+// along; they take their own log10.  A caller that arrives while all lanes are busy waits for a leader to take it, or for a lane.
+// Under load the batches grow by themselves; a lone caller runs its region at once, on its own thread, with no hand-off.
+namespace {
+struct MuxReq {
+  const void* rs; size_t rb; const void* hs; size_t hb; int mode;
+  PhmmParsed parsed;
+  uint64_t pairs = 0;
+  float* raw = nullptr;                 // the caller's out_raw, or this request's own buffer
+  std::vector<float> raw_own;
+  std::vector<double> r64;              // fp64 values of the pairs (filled when the batch rescued something)
+  uint64_t resc = 0;
+  accg_counters cnt{};
+  int status = ACCG_OK; std::string err;
+  bool all5 = true;                     // every read passes the five-operation form's range tests
+  bool taken = false, done = false;
+  std::condition_variable cv;
+};
+}  // namespace
+struct accg_phmm_mux {
+  std::mutex mu;
+  std::deque<MuxReq*> q;
+  std::vector<accg_ctx*> lanes;
+  std::vector<int> free_lanes;
+  int max_regions = 64;
+  uint64_t max_pairs = 1u << 20;
+  uint64_t batches = 0, regions = 0;    // statistics (accg_phmm_mux_stats)
+};
+
+extern "C" int accg_phmm_mux_create(int device, int lanes, int max_regions, accg_phmm_mux** out) {
+  if (!out || lanes < 1 || lanes > 16 || max_regions < 1) return ACCG_ERR_BAD_ARG;
+  *out = nullptr;
+  std::unique_ptr<accg_phmm_mux> m(new accg_phmm_mux);
+  m->max_regions = max_regions;
+  for (int i = 0; i < lanes; i++) {
+    accg_ctx* c = nullptr;
+    const int st = accg_init(device, &c);
+    if (st != ACCG_OK) { for (accg_ctx* x : m->lanes) accg_shutdown(x); return st; }
+    m->lanes.push_back(c);
+    m->free_lanes.push_back(i);
+  }
+  *out = m.release();
+  return ACCG_OK;
+}
+extern "C" void accg_phmm_mux_destroy(accg_phmm_mux* m) {
+  if (!m) return;
+  for (accg_ctx* c : m->lanes) accg_shutdown(c);
+  delete m;
+}
+extern "C" void accg_phmm_mux_stats(accg_phmm_mux* m, uint64_t* batches, uint64_t* regions) {
+  if (!m) return;
+  std::lock_guard<std::mutex> g(m->mu);
+  if (batches) *batches = m->batches;
+  if (regions) *regions = m->regions;
+}
+
+namespace {
+// a leader's batch on its lane; n == 1 or a failed batch: every request on its own, so that an error lands on the region that caused it
+void mux_run(accg_phmm_mux* m, int lane, std::vector<MuxReq*>& batch, bool alone) {
+  accg_ctx* c = m->lanes[(size_t)lane];
+  const size_t n = batch.size();
+  // No OpenMP team under a leader: leaders are whatever caller threads come by, and each would become the root of a thread pool of its
+  // own (sixteen callers leading in turn: sixteen pools spinning against each other -- a batch of eight regions took 3.4 ms).  The
+  // callers ARE the host parallelism here: each has parsed its own region and takes its own log10.
+  struct Threads { int prev; explicit Threads(int t) : prev(tls_host_threads) { tls_host_threads = t; } ~Threads() { tls_host_threads = prev; } } threads(1);
+  auto run = [&](MuxReq* const* reqs, size_t k) {
+    std::vector<const void*> rs(k), hs(k); std::vector<size_t> rb(k), hb(k); std::vector<const PhmmParsed*> pre(k); std::vector<ResultDst> dst(k);
+    for (size_t i = 0; i < k; i++) {
+      MuxReq& R = *reqs[i];
+      rs[i] = R.rs; rb[i] = R.rb; hs[i] = R.hs; hb[i] = R.hb; pre[i] = &R.parsed;
+      dst[i] = ResultDst{R.raw, nullptr, &R.cnt, R.pairs, 0, R.r64.data(), &R.resc};
+    }
+    return region_call(c, (int)k, rs.data(), rb.data(), hs.data(), hb.data(), reqs[0]->mode, dst.data(), k, nullptr, nullptr, nullptr, pre.data(), alone);
+  };
+  int st = run(batch.data(), n);
+  if (st != ACCG_OK && n > 1) {
+    for (MuxReq* R : batch) { R->status = run(&R, 1); if (R->status != ACCG_OK) R->err = accg_last_hip_error(); }
+    return;
+  }
+  for (MuxReq* R : batch) { R->status = st; if (st != ACCG_OK) R->err = accg_last_hip_error(); }
+}
+}  // namespace
+
+extern "C" int accg_phmm_mux_region(accg_phmm_mux* m, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes, int mode,
+                                    float* out_raw, double* out_log10, accg_counters* counters) {
+  if (!m) return ACCG_ERR_NOT_INITIALISED;
+  if (!reads_ser || !haps_ser) return ACCG_ERR_BAD_ARG;
+  MuxReq me;
+  me.rs = reads_ser; me.rb = reads_bytes; me.hs = haps_ser; me.hb = haps_bytes; me.mode = mode;
+  // this caller's share of the host work, on its own thread: parse, validate, range tests
+  parse_region(reads_ser, reads_bytes, haps_ser, haps_bytes, me.parsed);
+  if (me.parsed.nr < 0) return me.parsed.nr;
+  if (me.parsed.nh < 0) return me.parsed.nh;
+  me.pairs = (uint64_t)me.parsed.nr * (uint64_t)me.parsed.nh;
+  for (uint8_t f : me.parsed.form) me.all5 &= f == 5;
+  if (out_raw) me.raw = out_raw; else { me.raw_own.resize((size_t)me.pairs); me.raw = me.raw_own.data(); }
+  if (out_log10) me.r64.resize((size_t)me.pairs);
+  {
+    std::unique_lock<std::mutex> lk(m->mu);
+    m->q.push_back(&me);
+    while (!me.done) {
+      if (me.taken || m->free_lanes.empty()) { me.cv.wait(lk); continue; }
+      // lead: everything queued in this request's mode, in arrival order, this request included
+      // (the lowest free lane: a lone caller always runs on lane 0, whose streams were made first and sit on hardware queues of their own)
+      const auto lo = std::min_element(m->free_lanes.begin(), m->free_lanes.end());
+      const int lane = *lo;
+      m->free_lanes.erase(lo);
+      std::vector<MuxReq*> batch;
+      uint64_t pairs = 0;
+      for (auto it = m->q.begin(); it != m->q.end() && (int)batch.size() < m->max_regions;) {
+        MuxReq* R = *it;
+        // (one arithmetic mode per batch; and a batch's fp64 rescue runs the five-operation form only if ALL its reads pass that form's
+        // range tests, so regions are only combined with regions of the same kind: a region's bits do not depend on its company)
+        if (R->mode == me.mode && R->all5 == me.all5 && (batch.empty() || pairs + R->pairs <= m->max_pairs)) {
+          R->taken = true; batch.push_back(R); pairs += R->pairs; it = m->q.erase(it);
+        } else ++it;
+      }
+      m->batches++; m->regions += batch.size();
+      // (the speculative fp64 pass of a small batch, run_spec, is for a caller that has the device to itself: ten times the fp64 work
+      // and a second hardware queue are well spent on an idle chip and wasted on a shared one)
+      const bool alone = m->free_lanes.size() + 1 == m->lanes.size() && m->q.empty();
+      lk.unlock();
+      mux_run(m, lane, batch, alone);
+      lk.lock();
+      for (MuxReq* R : batch) { R->done = true; if (R != &me) R->cv.notify_one(); }
+      m->free_lanes.push_back(lane);
+      for (MuxReq* R : m->q) R->cv.notify_one();              // whoever arrived meanwhile: the first to wake up leads the next batch
+    }
+  }
+  if (me.status != ACCG_OK) { set_error_text(me.err.c_str()); return me.status; }
+  if (out_log10) {
+    const HostTables& t = host_tables();
+    const float* rw = me.raw; const double* rd = me.r64.data();
+    for (size_t i = 0; i < (size_t)me.pairs; i++)     // FalconPairHMM.cpp:83-90 / PairHMMWorker.cpp:176-190
+      out_log10[i] = rw[i] < PHMM_MIN_ACCEPTED ? log10(rd[i]) - t.log10_init_d : (double)(log10f(rw[i]) - t.log10_init_f);
+  }
+  if (counters) *counters = me.cnt;
+  return ACCG_OK;
 }

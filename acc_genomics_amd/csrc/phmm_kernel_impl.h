@@ -766,7 +766,9 @@ __device__ __forceinline__ bool phmm_job(const PhmmArgs<T>& a, uint32_t work_bas
   }
   for (int j = 0; j < n_list; j++) {
     const uint32_t col = __builtin_amdgcn_readlane(col_l, j);
-    if (RESCUE) {   // keep this haplotype only if one of the wavefront's reads underflowed in fp32 against it
+    // keep this haplotype only if one of the wavefront's reads underflowed in fp32 against it (a.raw == nullptr: a speculative fp64
+    // pass NEXT TO the fp32 sweep of a small batch, phmm_host.cpp run_spec -- every haplotype, nothing counted here)
+    if (RESCUE && a.raw) {
       const bool under = have && g < NG && l == 0 && a.raw[out_base + col] < PHMM_MIN_ACCEPTED;
       const unsigned long long m = __ballot(under);
       if (m == 0) continue;

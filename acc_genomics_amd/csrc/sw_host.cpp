@@ -207,6 +207,7 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   a.cig_packed = b->d_cig_packed; a.cig_start = b->d_cig_start; a.cig_total = b->d_cig_total;
   ACCG_HIP(hipMemsetAsync(b->d_cig_total, 0, sizeof(unsigned long long), s));
   accg_ctx* c = b->ctx;
+  ACCG_HIP(ctx_need_aux(c));
   hipStream_t st = c->aux[0];
   { const char* e = getenv("ACCG_SW_TRACE_SAME_STREAM"); if (e && e[0] == '1') st = s; }   // A/B knob: backtrace behind its fill, no overlap
   ACCG_HIP(ctx_fork(c));                                   // the trace stream starts behind everything queued so far (the memset)

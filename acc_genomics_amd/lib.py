@@ -53,6 +53,12 @@ def load():
     L.accg_phmm_ring_submit_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.c_int, C.POINTER(C.c_uint64)]
     L.accg_phmm_ring_wait.argtypes = [vp, C.c_uint64, vp, vp, C.POINTER(Counters)]
     L.accg_phmm_ring_destroy.argtypes = [vp]
+    L.accg_phmm_mux_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.accg_phmm_mux_region.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp, C.POINTER(Counters)]
+    L.accg_phmm_mux_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.accg_phmm_mux_stats.restype = None
+    L.accg_phmm_mux_destroy.argtypes = [vp]
+    L.accg_phmm_mux_destroy.restype = None
     L.accg_phmm_batch_create.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
     for n in ("accg_phmm_batch_pairs", "accg_phmm_batch_cells", "accg_phmm_batch_algorithmic_bytes", "accg_phmm_batch_jobs"):
         getattr(L, n).restype = C.c_uint64

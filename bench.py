@@ -618,6 +618,30 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
         out["c3_stream_threaded"] = {"regions": n_th, "regions_per_ticket": G, "tickets_in_flight": S_th, "ms_total": t_thr * 1e3, "value": th_cells / t_thr / 1e9,
                                      "unit": "GCUPS", "what": "accg_phmm_ring_create_threaded: %d configs[3] regions, the host half of every ticket and its download + "
                                                               "log10 on the worker thread of its slot, one caller thread, median of 3 passes" % n_th}
+        # The reference's own entry points at the reference's granularity: ONE region per blocking call, T native caller threads at once
+        # (tests/cpp/dropin_bench.cpp): the task plugin exactly as an accelerator manager drives it (create -> setInput -> prepare ->
+        # compute -> destroy per request, pairhmm/task/xlnx/PairHMMTask.cpp:27-143), accg_phmm_mux_region (what the plugin, compute_fpga
+        # and FalconPairHMM::computePairhmm sit on), and accg_phmm_region with one context per thread (no combining).
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_dropin as BD
+            LD = BD.load()
+            n_dr = 4 * n_c3
+            cells_dr = st_cells if n_dr == n_st else None
+            dr = {"regions": n_dr, "what": "one configs[3] region (128 reads x 16 haplotypes) per blocking call over the first %d regions, T native caller "
+                                           "threads, best of 3 passes after a warm-up pass; wire blobs in host memory in, results in host memory out" % n_dr,
+                  "entry_points": {}}
+            for key, what, want_l10 in (("task_plugin", 1, False), ("accg_phmm_mux_region", 4, True), ("accg_phmm_region_ctx_per_thread", 0, True)):
+                rows = {}
+                for T in (1, 4, 16):
+                    sec, _, _ = BD.run(LD, ser2[:n_dr], what, T, passes=3, want_raw=True, want_log10=want_l10)
+                    rows["threads_%d" % T] = {"us_per_region": sec / n_dr * 1e6, "value": cells_dr / sec / 1e9, "unit": "GCUPS"}
+                dr["entry_points"][key] = rows
+            dr["compute_fpga_1_thread"] = (lambda sec: {"us_per_region": sec / n_dr * 1e6, "value": cells_dr / sec / 1e9, "unit": "GCUPS"})(BD.run(LD, ser2[:n_dr], 2, 1, passes=3, want_raw=True)[0])
+            dr["FalconPairHMM_computePairhmm_1_thread"] = (lambda sec: {"us_per_region": sec / n_dr * 1e6, "value": cells_dr / sec / 1e9, "unit": "GCUPS"})(BD.run(LD, ser2[:n_dr], 3, 1, passes=3, want_log10=True)[0])
+            out["dropin"] = dr
+        except (OSError, ImportError, RuntimeError) as e:        # the driver library is test infrastructure: its absence must not take the line down
+            out["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
     out["note"] = "host memory to host memory, parse + job sizing + upload + kernels + download + log10 all inside; not the headline value"
     return out
 
@@ -836,6 +860,25 @@ def main():
             "e2e": e2e,
             "c3": c3, "sw": sw, "smem": smem, "bwasw": bwasw,
         }
+        # the figures of the legs that a reader of the line's top level should not have to dig for (scalars only)
+        def dig(d, *keys):
+            for k in keys:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d
+        line.update({
+            "dropin_task_plugin_gcups_1_thread": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_1", "value"),
+            "dropin_task_plugin_gcups_4_threads": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_4", "value"),
+            "dropin_task_plugin_gcups_16_threads": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_16", "value"),
+            "dropin_task_plugin_us_per_region_1_thread": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_1", "us_per_region"),
+            "dropin_mux_region_gcups_1_thread": dig(e2e, "dropin", "entry_points", "accg_phmm_mux_region", "threads_1", "value"),
+            "dropin_mux_region_gcups_16_threads": dig(e2e, "dropin", "entry_points", "accg_phmm_mux_region", "threads_16", "value"),
+            "dropin_region_ctx_per_thread_gcups_16_threads": dig(e2e, "dropin", "entry_points", "accg_phmm_region_ctx_per_thread", "threads_16", "value"),
+            "e2e_c3_stream_threaded_gcups": dig(e2e, "c3_stream_threaded", "value"),
+            "c3_gcups": dig(c3, "value"), "sw_gcups": dig(sw, "value"), "sw_with_cigar_gcups": dig(sw, "with_cigar", "value"),
+            "smem_mreads_per_s": dig(smem, "value"), "bwasw_mseeds_per_s": dig(bwasw, "value"),
+        })
     batch.close()
     comm.close()
     ctx.close()

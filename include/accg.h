@@ -105,6 +105,21 @@ int accg_phmm_ring_submit_many(accg_phmm_ring* ring, int n_regions, const void* 
 int accg_phmm_ring_wait(accg_phmm_ring* ring, uint64_t ticket, float* out_raw, double* out_log10, accg_counters* counters);
 void accg_phmm_ring_destroy(accg_phmm_ring* ring);
 
+/* Regions from CONCURRENT blocking callers -- the reference's own calling pattern: compute_fpga / FalconPairHMM::computePairhmm hand over
+ * one region per blocking call (pairhmm/host/PairHMMFpga.cpp:125-162, pairhmm/xlnx/host/FalconPairHMM.cpp:1184-1193) and an accelerator
+ * manager runs one PairHMM task per request, several at a time (pairhmm/task/xlnx/PairHMMTask.cpp:27-143).  accg_phmm_mux_region has the
+ * arguments, results and errors of accg_phmm_region (bit for bit) and may be called from any number of threads at once: a caller
+ * parses its own region and either leads one device batch of everything queued at that moment, on one of the mux's `lanes` contexts
+ * (2 or 3: the host half of one batch behind the device half of another), or is taken along by a leader.  A lone caller runs at once on
+ * its own thread.  max_regions caps a batch.  The blobs must stay untouched until the call returns (as for any blocking call). */
+typedef struct accg_phmm_mux accg_phmm_mux;
+int accg_phmm_mux_create(int device, int lanes, int max_regions, accg_phmm_mux** out);
+int accg_phmm_mux_region(accg_phmm_mux* mux, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes, int mode,
+                         float* out_raw, double* out_log10, accg_counters* counters);
+/* device batches run and regions served so far (regions / batches = how many callers a leader took along on average) */
+void accg_phmm_mux_stats(accg_phmm_mux* mux, uint64_t* batches, uint64_t* regions);
+void accg_phmm_mux_destroy(accg_phmm_mux* mux);      /* no call may be in progress */
+
 /* The same region entirely in fp64 (compute_fp_avxd, avx_impl.h:6; use_double, FalconPairHMM.cpp:82): raw x 2^1020. */
 int accg_phmm_region_f64(accg_ctx* ctx, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
                          double* out_raw64);

@@ -7,7 +7,10 @@
 //   what = 1: the task plugin of libaccg_compat.so per region: create() -> setInput x 3 -> prepare() -> compute() -> output block 0 -> destroy()
 //   what = 2: compute_fpga (not re-entrant, like the reference's: threads must be 1)
 //   what = 3: FalconPairHMM::computePairhmm, one object per caller thread (final log10 likelihoods; out_raw stays untouched)
+//   what = 4: accg_phmm_mux_region on one mux shared by all caller threads (include/accg.h); lanes = ACCG_MUX_LANES or 6
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <chrono>
@@ -24,6 +27,7 @@ struct Shared {
   const void* const* rs; const size_t* rb; const void* const* hs; const size_t* hb;
   const uint64_t* out_off;      // per region: index of its first pair in out_raw / out_log10
   float* out_raw; double* out_log10;
+  accg_phmm_mux* mux = nullptr;
   std::atomic<int> next{0};
   std::atomic<int> failed{0};
 };
@@ -55,6 +59,9 @@ void caller(Shared* S, accg_ctx* ctx, FalconPairHMM* falcon, const std::vector<p
       if (S->what == 0) {
         accg_counters c;
         if (accg_phmm_region(ctx, S->rs[i], S->rb[i], S->hs[i], S->hb[i], ACCG_PHMM_FAST, raw, l10, &c) != ACCG_OK) { S->failed++; return; }
+      } else if (S->what == 4) {
+        accg_counters c;
+        if (accg_phmm_mux_region(S->mux, S->rs[i], S->rb[i], S->hs[i], S->hb[i], ACCG_PHMM_FAST, raw, l10, &c) != ACCG_OK) { S->failed++; return; }
       } else if (S->what == 1) {
         task_host::Task* t = create();
         const uint64_t num_cell = 0;
@@ -86,7 +93,7 @@ void caller(Shared* S, accg_ctx* ctx, FalconPairHMM* falcon, const std::vector<p
 // out_raw / out_log10 (nullable): every region's results at out_off[region], from the last pass.
 extern "C" int dropin_bench(int what, int threads, int n_regions, const void* const* rs, const size_t* rb, const void* const* hs, const size_t* hb,
                             const uint64_t* out_off, int passes, float* out_raw, double* out_log10, double* best_s) {
-  if (what < 0 || what > 3 || threads < 1 || threads > 256 || n_regions < 1 || passes < 1 || !best_s || (what == 2 && threads != 1)) return -1;
+  if (what < 0 || what > 4 || threads < 1 || threads > 256 || n_regions < 1 || passes < 1 || !best_s || (what == 2 && threads != 1)) return -1;
   std::vector<accg_ctx*> ctxs;
   std::vector<FalconPairHMM*> falcons;
   std::vector<pairhmmInput> inputs;
@@ -99,10 +106,15 @@ extern "C" int dropin_bench(int what, int threads, int n_regions, const void* co
       for (int i = 0; i < n_regions; i++) to_input(rs[i], hs[i], inputs[(size_t)i]);
     }
   } catch (...) { rc = -1; }
+  accg_phmm_mux* mux = nullptr;
+  if (what == 4 && rc == 0) {
+    const char* l = getenv("ACCG_MUX_LANES");
+    if (accg_phmm_mux_create(0, l && atoi(l) > 0 ? atoi(l) : 6, 64, &mux) != ACCG_OK) rc = -1;
+  }
   double best = -1;
   for (int p = 0; p < passes + 1 && rc == 0; p++) {       // (one untimed pass first)
     Shared S;
-    S.what = what; S.n_regions = n_regions; S.rs = rs; S.rb = rb; S.hs = hs; S.hb = hb; S.out_off = out_off; S.out_raw = out_raw; S.out_log10 = out_log10;
+    S.mux = mux; S.what = what; S.n_regions = n_regions; S.rs = rs; S.rb = rb; S.hs = hs; S.hb = hb; S.out_off = out_off; S.out_raw = out_raw; S.out_log10 = out_log10;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int t = 1; t < threads; t++) th.emplace_back(caller, &S, what == 0 ? ctxs[(size_t)t] : nullptr, what == 3 ? falcons[(size_t)t] : nullptr, &inputs);
@@ -111,6 +123,12 @@ extern "C" int dropin_bench(int what, int threads, int n_regions, const void* co
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (S.failed.load()) rc = -1;
     if (p > 0 && (best < 0 || s < best)) best = s;
+  }
+  if (mux) {
+    uint64_t nb = 0, nr = 0;
+    accg_phmm_mux_stats(mux, &nb, &nr);
+    if (getenv("ACCG_TRACE_MUX")) fprintf(stderr, "mux: %llu regions in %llu batches\n", (unsigned long long)nr, (unsigned long long)nb);
+    accg_phmm_mux_destroy(mux);
   }
   for (accg_ctx* c : ctxs) accg_shutdown(c);
   for (FalconPairHMM* f : falcons) delete f;

@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-WHAT = {0: "accg_phmm_region (one context per thread)", 1: "task plugin create/prepare/compute/destroy", 2: "compute_fpga", 3: "FalconPairHMM::computePairhmm"}
+WHAT = {0: "accg_phmm_region (one context per thread)", 1: "task plugin create/prepare/compute/destroy", 2: "compute_fpga", 3: "FalconPairHMM::computePairhmm", 4: "accg_phmm_mux_region (one mux)"}
 
 
 def load():
@@ -48,7 +48,7 @@ if __name__ == "__main__":
     from acc_genomics_amd import synth
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     Ts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 4, 16]
-    Ws = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 3]
+    Ws = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 3, 4]
     regs = [bench.c3_region(k) for k in range(N)]
     ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
     cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs)
@@ -57,5 +57,5 @@ if __name__ == "__main__":
         for T in Ts:
             if w == 2 and T != 1:
                 continue
-            s, _, _ = run(L, ser, w, T, want_raw=(w != 3), want_log10=(w in (0, 3)))
+            s, _, _ = run(L, ser, w, T, want_raw=(w != 3), want_log10=(w in (0, 3, 4)))
             print("%-48s %2d threads: %8.3f ms for %d regions = %6.1f us per region, %6.0f GCUPS" % (WHAT[w], T, s * 1e3, N, s / N * 1e6, cells / s / 1e9), flush=True)
