@@ -79,7 +79,8 @@ extern "C" int accg_sw_batch_create(accg_ctx* ctx, int n, const uint8_t* refs, s
     // ... and only up to 16 positions per lane: the decision record keeps one bit per position in each 16-bit half of its planes
     // (K = 20 / 24 exist for sequences over 1024 on 64 lanes; with small-magnitude weights those used to pass the range test, and
     // their CIGARs came out wrong while score and end cell were right -- found by tools/fuzz_sw.py)
-    const bool p16 = hi <= 32000 && lo >= -32000 && std::abs(w_match) < 16000 && std::abs(w_mismatch) < 16000 && Kk <= 16;
+    static const bool no16 = [] { const char* e = getenv("ACCG_SW_P16"); return e && e[0] == '0'; }();     // A/B knob: int32 arithmetic for every pair
+    const bool p16 = !no16 && hi <= 32000 && lo >= -32000 && std::abs(w_match) < 16000 && std::abs(w_mismatch) < 16000 && Kk <= 16;
     items[k] = {(uint32_t)k, Kk, lpp, ns, p16, lia};
     b->cells += (uint64_t)rl * al;
     b->algo_bytes += (uint64_t)rl + al + 16;
@@ -222,6 +223,8 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
       const int h = (int)(k & 1);
       a.bt = reinterpret_cast<uint4*>(reinterpret_cast<char*>(b->d_bt) + (size_t)h * (b->bt_bytes / 2));
       if (used[h]) ACCG_HIP(hipStreamWaitEvent(s, c->ev_join[h], 0));      // the walk over this half's previous record is through
+      static const int dbg = [] { const char* e = getenv("ACCG_SW_BT_DEBUG"); return e ? atoi(e) : 0; }();   // measurement aid (tools/exp_sw_bt.py): 1 = no trace kernels, 2 = no record stores either; the CIGARs of such a run are garbage
+      if (dbg) { if (dbg == 2) a.bt = nullptr; ACCG_HIP(sw_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, true, a, w0, n, w0, l.sweep_cap, s)); continue; }
       ACCG_HIP(sw_launch(l.K, l.lpp, l.pack16, l.lane_is_alt, true, a, w0, n, w0, l.sweep_cap, s));
       ACCG_HIP(hipEventRecord(c->ev_fork, s));
       ACCG_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
   __syncthreads();
 
   // ---- sweep ---------------------------------------------------------------------------------------
+  unsigned dbg_acc = 0;
   for (int t = 1; t <= t_end; t++) {
     // hand-off from the lane on the left (all lanes, also the switched-off ones: their registers are frozen)
     d_in = h_in;
@@ -238,12 +239,15 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
         fo = VT::adds(hn, opn_s); Ho[k] = fo;
       }
       h_last = hup; f_last = f;
-      if (BT) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + LPP) + t) * LPP + l] =
-          make_uint4(pf, pg, pn, pd);
+      if (BT) {
+        if (a.bt) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + LPP) + t) * LPP + l] = make_uint4(pf, pg, pn, pd);
+        else dbg_acc ^= pf ^ (pg * 3u) ^ (pn * 5u) ^ (pd * 7u);       // measurement aid (ACCG_SW_BT_DEBUG=2, tools/exp_sw_bt.py): planes formed, nothing stored
+      }
       if (l == LPP - 1) my_log[i] = VT::bits(hup);
     }
   }
   __syncthreads();
+  if (BT && !a.bt && dbg_acc == 0x12345u) a.score[0] = (int)dbg_acc;
 
   // ---- end cell (calculateCigarOneBatch, FalconSW_AVX.cpp:2314-2339) ---------------------------------
   // "edge" candidates: H[lane-seq end][sweep index s], s = 1..ns (from the log);
