@@ -70,6 +70,9 @@ struct accg_ctx {
   // set for the duration of a blocking region call (accg_phmm_region, a mux leader's batch): the batch is created for ONE pass whose
   // latency is what counts -- a batch small enough to leave most of the chip idle computes its fp64 values speculatively next to
   // the fp32 sweep instead of behind it (phmm_host.cpp: run_spec)
+  // a page of host-visible words for device-written flags (made at first use; phmm_host.cpp: the rescue probe of a batch that is run repeatedly)
+  uint32_t* h_flags = nullptr;
+  uint32_t flag_next = 0;
   bool oneshot = false;
   bool alone = true;            // ... and no other caller is known to share the device right now (a mux tells: false while other lanes are busy)
   int wall_khz = 100000;        // rate of the device's constant wall clock (wall_clock64): 100 MHz on every gfx9

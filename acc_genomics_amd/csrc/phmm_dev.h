@@ -180,6 +180,7 @@ struct PhmmPlanArgs {
   uint32_t* counts;               // jobs written per class
   uint32_t* flagged;              // scratch, one slot per read
   uint32_t class_off[PHMM_RESCUE_CLASSES + 1];
+  uint32_t* host_flag;            // nullable, host-visible: set to 1 when some read of the batch is flagged (phmm_host.cpp: rescue probe)
   uint32_t pairs;                 // 1: every group's items come in pairs for workgroups of two wavefronts (an odd last one is followed by an empty item)
 };
 hipError_t phmm_rescue_plan_launch(const PhmmPlanArgs& p, uint32_t n_regions, hipStream_t s);

@@ -121,6 +121,7 @@ extern "C" void accg_shutdown(accg_ctx* c) {
   if (c->ev_fork_t) hipEventDestroy(c->ev_fork_t);
   c->pool.drain();
   if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->h_flags) hipHostFree(c->h_flags);
   if (c->tab_mem) hipFree(c->tab_mem);
   delete c;
 }
@@ -409,6 +410,16 @@ struct accg_phmm_batch {
   std::vector<uint32_t> spec_counts;                      // PHMM_RESCUE_CLASSES words, uploaded (what the planner's counters would hold)
   DevBuf<PhmmWork> d_spec_jobs;
   DevBuf<uint32_t> d_spec_counts;
+  // Rescue probe of a batch that is run again and again (a device-resident batch: bench.py, pipelines).  Whether a pass has anything to
+  // rescue depends on the batch's bytes and the arithmetic mode only, so ONE complete pass that flagged nothing settles it for all later
+  // ones: from its second pass on the planner reports "something flagged" into a host-visible word, an event marks the end of that pass's
+  // tail, and once the host sees the event done and the word still 0 it stops queueing the planner and the (empty) fp64 launches for
+  // this batch in this mode -- two dependent launches and their gaps per pass (configs[1]: some 20 us of 275).
+  int rescue_known[2] = {0, 0};      // per mode: 0 not known yet, 1 never rescues, 2 rescues
+  int probe_runs[2] = {0, 0};
+  hipEvent_t ev_probe[2] = {nullptr, nullptr};
+  uint32_t* probe_flag[2] = {nullptr, nullptr};
+  bool probe_armed[2] = {false, false};
   bool kernel_copies = false;    // a small batch: upload and results travel by copy kernels on the stream (accg_ctx::kernel_copy_max)
   bool results_late = false;     // ring: the downloads are queued by results_finish, not behind the kernels
   bool results_fetched = false;  // the raw results (and, for kernel copies, the fp64 values) of the last pass are in the staging block
@@ -782,8 +793,12 @@ void partition(accg_phmm_batch& b) {
   // Two passes over the regions.  The first, serial and cheap, cuts each region's haplotypes into runs and hands out the places of
   // what the second one writes (run table, haplotype lists, streams, jobs); the second fills them region by region, independently,
   // on the host's threads.
-  struct RegPlan { std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens; uint32_t chunk0 = 0, ids0 = 0, job0 = 0, n_jobs = 0; size_t stream0 = 0; };
+  struct RegPlan { std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens; uint32_t chunk0 = 0, ids0 = 0, job0 = 0, n_jobs = 0, rchunk0 = 0; size_t stream0 = 0; };
   std::vector<RegPlan> plan(b.regions.size());
+  // (measured and dropped, round 4: rescue items of ONE haplotype each instead of the sweep's runs for batches of up to a few hundred
+  // regions -- a 134-region configs[3] shard: planner + rescue 0.481 -> 0.491 ms, 1024 regions 2.52 -> 2.72: no gain at any size)
+  const bool rescue_split = false;
+  uint32_t rchunk_total = 0;
   {
     uint32_t chunk0 = 0, ids0 = 0; size_t stream0 = 0;
     for (size_t ri = 0; ri < b.regions.size(); ri++) {
@@ -796,18 +811,27 @@ void partition(accg_phmm_batch& b) {
         cap_all = std::max(cap_all, (P.lens[c] + 63) / 64 * 64); hmax_all = std::max(hmax_all, P.runs[c].second);
         ids0 += P.runs[c].second;
         stream0 += (P.lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16;
-        b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((P.lens[c] + 63) / 64 * 64));
-        b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)P.runs[c].second);
+        if (!rescue_split) {
+          b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((P.lens[c] + 63) / 64 * 64));
+          b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)P.runs[c].second);
+        }
+      }
+      if (rescue_split) {
+        for (uint32_t k = 0; k < r.n_haps; k++) b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((b.hp[r.hap0 + k].len + 2 + 63) / 64 * 64));
+        b.rescue_haps_cap = std::max(b.rescue_haps_cap, 1);
       }
       chunk0 += (uint32_t)P.runs.size();
-      b.regions_dev[ri] = {r.read0, r.n_reads, P.chunk0, (uint32_t)P.runs.size(), r.n_haps, 0};
+      const uint32_t n_rchunks = rescue_split ? r.n_haps : (uint32_t)P.runs.size();
+      P.rchunk0 = rchunk_total;
+      rchunk_total += n_rchunks;
+      b.regions_dev[ri] = {r.read0, r.n_reads, P.rchunk0, n_rchunks, r.n_haps, 0};
       {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
         uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
         for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
-        for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)((P.runs.size() + 1) / 2 * 2);   // (room for pairs)
+        for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)((n_rchunks + 1) / 2 * 2);   // (room for pairs)
       }
     }
-    b.chunks_dev.resize(chunk0); b.chunk_stream16.resize(chunk0); b.chunk_stream_len.resize(chunk0);
+    b.chunks_dev.resize(rchunk_total); b.chunk_stream16.resize(chunk0); b.chunk_stream_len.resize(chunk0);
     b.hap_ids.resize(ids0);
     b.streams.assign(stream0, 0);
   }
@@ -835,7 +859,9 @@ void partition(accg_phmm_batch& b) {
     for (size_t c = 0; c < runs.size(); c++) {
       const auto& run = runs[c];
       ids0[c] = idp;
-      b.chunks_dev[P.chunk0 + c] = {idp, run.second};
+      // (the rescue's chunk table: the sweep's runs, or one entry per haplotype -- a region's haplotypes sit in hap_ids in their own order)
+      if (!rescue_split) b.chunks_dev[P.rchunk0 + c] = {idp, run.second};
+      else for (uint32_t k = 0; k < run.second; k++) b.chunks_dev[P.rchunk0 + run.first + k] = {idp + k, 1u};
       for (uint32_t k = 0; k < run.second; k++) b.hap_ids[idp++] = r.hap0 + run.first + k;
       // the run's stream: [marker][codes] per haplotype, a last marker, zeros (phmm_dev.h)
       b.chunk_stream16[P.chunk0 + c] = (uint32_t)(sp / 16);
@@ -1034,10 +1060,33 @@ int launch_f32(accg_phmm_batch* b, int mode, hipEvent_t ev_begin = nullptr, hipE
   return ACCG_OK;
 }
 // on_tail: on the context's tail stream and its forked streams (a pipelined pass, run_direct) instead of the main stream's
+bool graphs_wanted();
 int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
   hipStream_t s = on_tail ? b->ctx->tail : b->ctx->stream;
   hipStream_t* const aux = on_tail ? b->ctx->aux_t : b->ctx->aux;
+  // the rescue probe (see accg_phmm_batch::rescue_known); ACCG_PHMM_PROBE=0 turns it off
+  const int mi = mode == ACCG_PHMM_STRICT ? 1 : 0;
+  static const bool probe_off = [] { const char* e = getenv("ACCG_PHMM_PROBE"); return e && e[0] == '0'; }();
+  bool arm = false;
+  if (!probe_off && !graphs_wanted()) {
+    if (b->rescue_known[mi] == 0 && b->probe_armed[mi] && hipEventQuery(b->ev_probe[mi]) == hipSuccess)
+      b->rescue_known[mi] = __atomic_load_n(b->probe_flag[mi], __ATOMIC_ACQUIRE) ? 2 : 1;
+    (void)hipGetLastError();                    // (hipErrorNotReady of the query is not an error)
+    if (b->rescue_known[mi] == 1) return ACCG_OK;
+    if (b->rescue_known[mi] == 0 && !b->probe_armed[mi] && b->probe_runs[mi]++ >= 1) {        // from the second pass in this mode on
+      accg_ctx* c = b->ctx;
+      if (!c->h_flags) {
+        ACCG_HIP(hipHostMalloc((void**)&c->h_flags, 4096, hipHostMallocCoherent));
+        memset(c->h_flags, 0, 4096);
+      }
+      b->probe_flag[mi] = c->h_flags + (c->flag_next++ % 1024u);
+      *b->probe_flag[mi] = 0u;
+      if (!b->ev_probe[mi]) ACCG_HIP(hipEventCreateWithFlags(&b->ev_probe[mi], hipEventDisableTiming));
+      arm = true;
+    }
+  }
   PhmmPlanArgs p;
+  p.host_flag = arm ? b->probe_flag[mi] : nullptr;
   p.regions = b->d_regions.p; p.chunks = b->d_chunks.p; p.sorted_reads = b->d_sorted_reads.p; p.rd = b->d_rd.p;
   p.rd_out = b->d_rd_out.p; p.read_flag = b->d_state.p; p.jobs = b->d_rescue_jobs.p; p.counts = b->d_state.p + state_counts(*b);
   p.flagged = b->d_flagged.p;
@@ -1117,6 +1166,7 @@ int launch_rescue(accg_phmm_batch* b, int mode, bool on_tail = false) {
     r.redo_count = b->d_state.p + state_redo(*b); r.redo_list = b->d_redo.p;
     ACCG_HIP(phmm_launch_redo_multi(redo_lds, r, rs, PHMM_REDO_GRID, s));
   }
+  if (arm) { ACCG_HIP(hipEventRecord(b->ev_probe[mi], s)); b->probe_armed[mi] = true; }
   return ACCG_OK;
 }
 
@@ -1606,6 +1656,27 @@ extern "C" int accg_phmm_batch_clock_ghz(accg_phmm_batch* b, float* ghz) {
   *ghz = h[1] ? (float)((double)h[0] / (double)h[1] * (double)wall_khz * 1e-6) : 0.f;
   return ACCG_OK;
 }
+// The per-row records of the five-operation sweep (phmm_prepare_rows) are written once, at batch creation -- a pure function of the
+// reads, like the haplotype streams the host lays out -- so a timed pass over a device-resident batch does not contain them.  This
+// times that kernel by itself (mean of `iters` launches on the context's stream), for a line that wants to state it next to its step.
+extern "C" int accg_phmm_batch_time_prepare(accg_phmm_batch* b, int iters, float* ms_per_run) {
+  if (!b || !ms_per_run || iters <= 0) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  *ms_per_run = 0.f;
+  if (!b->any_form5 || !b->n_rows) return ACCG_OK;
+  accg_ctx* c = b->ctx;
+  { const int stj = join_tail(b); if (stj != ACCG_OK) return stj; }
+  const PhmmArgs<float> pa = make_args<float>(*b, b->d_out.p, c->tab_f);
+  ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), nullptr, 0, c->stream));
+  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < iters; i++) ACCG_HIP(phmm_prepare_rows_launch(pa, (uint32_t)b->rd.size(), nullptr, 0, c->stream));
+  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
+  ACCG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_run = ms / iters;
+  return ACCG_OK;
+}
 extern "C" int accg_phmm_batch_time(accg_phmm_batch* b, int mode, int warmup, int iters, float* ms_per_run) {
   return accg_phmm_batch_time2(b, mode, 0, warmup, iters, ms_per_run);
 }
@@ -1718,6 +1789,7 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   hipStreamSynchronize(b->ctx->stream);
   if (b->ctx->tail && (b->tail_pending || b->alt.tail_pending || b->runs)) hipStreamSynchronize(b->ctx->tail);
   for (hipGraphExec_t& g : b->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  for (hipEvent_t& e : b->ev_probe) if (e) { hipEventDestroy(e); e = nullptr; }
   if (b->ev_sweep) hipEventDestroy(b->ev_sweep);
   if (b->tail_done) hipEventDestroy(b->tail_done);
   if (b->alt.tail_done) hipEventDestroy(b->alt.tail_done);

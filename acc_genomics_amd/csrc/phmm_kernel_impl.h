@@ -1536,6 +1536,7 @@ __global__ __launch_bounds__(256) void phmm_rescue_plan(PhmmPlanArgs p) {
   }
   __syncthreads();
   if (!s_any) return;
+  if (tid == 0 && p.host_flag) __hip_atomic_store(p.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   uint32_t* out = p.flagged + R.read0;
   for (uint32_t i0 = 0; i0 < R.n_reads; i0 += 256) {          // ordered compaction, 256 reads at a time
     const uint32_t i = i0 + tid;

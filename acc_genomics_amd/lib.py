@@ -68,6 +68,7 @@ def load():
     L.accg_phmm_batch_results_f64.argtypes = [vp, vp]
     L.accg_phmm_batch_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_phmm_batch_time2.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.accg_phmm_batch_time_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.accg_phmm_batch_time_in_step.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.accg_ctx_clock_ghz.argtypes = [vp, C.POINTER(C.c_float)]
     L.accg_phmm_batch_clock_ghz.argtypes = [vp, C.POINTER(C.c_float)]
@@ -273,6 +274,12 @@ class PhmmBatch:
         k, s = C.c_float(), C.c_float()
         _check(self.L.accg_phmm_batch_time_in_step(self.h, mode, iters, C.byref(k), C.byref(s)))
         return k.value, s.value
+
+    def time_prepare(self, iters=20):
+        """accg_phmm_batch_time_prepare: ms of the kernel that writes the per-row records at batch creation (0 if the batch has none)."""
+        ms = C.c_float()
+        _check(self.L.accg_phmm_batch_time_prepare(self.h, iters, C.byref(ms)))
+        return ms.value
 
     def clock_ghz(self):
         """accg_phmm_batch_clock_ghz: the shader clock held under the last sweep launch (its first wavefront's own measurement)."""

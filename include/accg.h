@@ -130,6 +130,9 @@ int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int warmup, in
 /* `iters` whole passes back to back with HIP events around each pass's fp32 sweep launches, on the stream they are launched on:
  * kernel_ms = mean of the dominant kernel measured INSIDE the step, step_ms = mean whole pass (same run, same clock state) */
 int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float* kernel_ms, float* step_ms);
+/* The per-row coefficient records of the fast sweep are written ONCE, at batch creation (a pure function of the reads, like the haplotype
+ * streams): a pass over a device-resident batch does not rewrite them.  This times the kernel that writes them, mean of `iters` launches. */
+int accg_phmm_batch_time_prepare(accg_phmm_batch* b, int iters, float* ms_per_run);
 /* the shader clock the device holds under load right now, in GHz: a ~0.3 ms full-chip fp32 kernel whose first wavefront reads the
  * shader-clock counter and the constant-rate wall clock at both ends */
 int accg_ctx_clock_ghz(accg_ctx* ctx, float* ghz);
