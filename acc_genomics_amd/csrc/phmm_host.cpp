@@ -420,6 +420,7 @@ struct accg_phmm_batch {
   hipEvent_t ev_probe[2] = {nullptr, nullptr};
   uint32_t* probe_flag[2] = {nullptr, nullptr};
   bool probe_armed[2] = {false, false};
+  bool timed_by_events = false;  // a ring ticket: the context's ev0 / ev1 bracket its pass (results_finish takes the device time from them)
   bool kernel_copies = false;    // a small batch: upload and results travel by copy kernels on the stream (accg_ctx::kernel_copy_max)
   bool results_late = false;     // ring: the downloads are queued by results_finish, not behind the kernels
   bool results_fetched = false;  // the raw results (and, for kernel copies, the fp64 values) of the last pass are in the staging block
@@ -908,7 +909,11 @@ void partition(accg_phmm_batch& b) {
     // Merge class: the jobs of the prepared five-operation sweep whose K lies in one window of phmm_launch_f32_multi and that have the
     // same workgroup size end up next to each other, ordered by lanes and K (= by rows per read), and can go out as ONE launch in fast mode.
     const int mc = merge_class(x.K, x.lpp, x.form, x.striped, x.wg);
-    const uint64_t key = ((uint64_t)(x.striped ? 1 : 0) << 63) | ((uint64_t)(mc & 15) << 59) | ((uint64_t)(x.lpp & 63) << 53) | ((uint64_t)(x.K & 31) << 48) |
+    // (lanes per read as log2(lanes / 8) in two bits: 8, 16, 32, 64 -> 0..3 -- the six low bits of the lane count itself made 64 a 0 and
+    // sent the longest jobs, reads of 513 to 1023 bases, to the back of the list)
+    static_assert(PHMM_MAX_K < 32, "K takes five bits of the job sort key");
+    const uint64_t lane_code = x.lpp >= 64 ? 3 : x.lpp >= 32 ? 2 : x.lpp >= 16 ? 1 : 0;
+    const uint64_t key = ((uint64_t)(x.striped ? 1 : 0) << 63) | ((uint64_t)(mc & 15) << 59) | (lane_code << 53) | ((uint64_t)(x.K & 31) << 48) |
                          ((uint64_t)(7 - x.form) << 45) | ((uint64_t)(x.wg & 3) << 43) | std::min<uint64_t>(x.cost, (1ull << 43) - 1);
     order[i] = {~key, (uint32_t)i};
   }
@@ -1724,6 +1729,11 @@ int results_finish(accg_phmm_batch* b, const ResultDst* dst, size_t n_dst) {
     ACCG_HIP(hipMemcpyAsync(stage + sizeof(unsigned long long), b->res_ptr, head, hipMemcpyDeviceToHost, b->ctx->stream));
     ACCG_HIP(hipStreamSynchronize(b->ctx->stream));
   }
+  if (b->timed_by_events) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, b->ctx->ev0, b->ctx->ev1) == hipSuccess) b->last_kernel_ns = (uint64_t)((double)ms * 1e6);
+    b->timed_by_events = false;
+  }
   unsigned long long nresc = 0, ticks = 0;
   memcpy(&ticks, stage, sizeof ticks);
   memcpy(&nresc, stage + sizeof ticks, sizeof nresc);
@@ -2013,7 +2023,13 @@ static int ring_submit_body(accg_phmm_ring* r, size_t slot, int n_regions, const
   if (st != ACCG_OK) return st;
   const auto t1 = std::chrono::steady_clock::now();
   b->graph_off = true;
+  // device time of the ticket (accg_counters::kernel_ns, what the reference prints its GCUPS from: FalconPairHMM.cpp:1214-1220): a small
+  // batch times itself on the device's wall clock (results_finish), a large one between two events on the slot's stream
+  const bool events = !b->kernel_copies;
+  if (events) ACCG_HIP(hipEventRecord(c->ev0, c->stream));
   st = accg_phmm_batch_run(b, mode);
+  if (st == ACCG_OK) st = join_tail(b);
+  if (events && st == ACCG_OK) { ACCG_HIP(hipEventRecord(c->ev1, c->stream)); b->timed_by_events = true; }
   const auto t2 = std::chrono::steady_clock::now();
   if (st == ACCG_OK) st = results_enqueue(b, r->threaded);
   if (st != ACCG_OK) { accg_phmm_batch_destroy(b); return st; }
@@ -2031,7 +2047,8 @@ extern "C" int accg_phmm_ring_submit_many(accg_phmm_ring* r, int n_regions, cons
   if (!r || !ticket || n_regions < 1 || !reads_ser || !reads_bytes || !haps_ser || !haps_bytes) return ACCG_ERR_BAD_ARG;
   const size_t slot = (size_t)(r->next_ticket % r->ctx.size());
   // the slot's previous ticket has not been waited for (a threaded slot's batch pointer belongs to its worker while a ticket is out)
-  if (r->threaded ? r->slot[slot]->busy : r->batch[slot] != nullptr) return ACCG_ERR_BAD_ARG;
+  if (r->threaded) { std::lock_guard<std::mutex> lk(r->slot[slot]->mu); if (r->slot[slot]->busy) return ACCG_ERR_BAD_ARG; }
+  else if (r->batch[slot] != nullptr) return ACCG_ERR_BAD_ARG;
   uint64_t pairs = 0; size_t blob = 0;
   for (int i = 0; i < n_regions; i++) {
     if (reads_bytes[i] < 4 || haps_bytes[i] < 4 || !reads_ser[i] || !haps_ser[i]) return ACCG_ERR_BAD_WIRE;
@@ -2051,8 +2068,8 @@ extern "C" int accg_phmm_ring_submit_many(accg_phmm_ring* r, int n_regions, cons
       S.rb.assign(reads_bytes, reads_bytes + n_regions); S.hb.assign(haps_bytes, haps_bytes + n_regions);
       S.n_regions = n_regions; S.mode = mode; S.pairs = pairs; S.blob = blob;
       S.status = ACCG_OK; S.err.clear(); S.done = false; S.has_work = true;
+      S.busy = true;
     }
-    S.busy = true;
     S.cv.notify_all();
   }
   *ticket = r->next_ticket++;
@@ -2070,12 +2087,12 @@ extern "C" int accg_phmm_ring_wait(accg_phmm_ring* r, uint64_t ticket, float* ou
   const size_t slot = (size_t)(ticket % r->ctx.size());
   if (r->threaded) {
     RingSlot& S = *r->slot[slot];
-    if (!S.busy) return ACCG_ERR_BAD_ARG;                     // waited for already
     {
       std::unique_lock<std::mutex> lk(S.mu);
+      if (!S.busy) return ACCG_ERR_BAD_ARG;                   // waited for already
       S.cv.wait(lk, [&] { return S.done; });
+      S.busy = false;
     }
-    S.busy = false;
     if (S.status != ACCG_OK) { set_error_text(S.err.c_str()); return S.status; }
     if (out_raw && !S.raw.empty()) memcpy(out_raw, S.raw.data(), S.raw.size() * sizeof(float));
     if (out_log10 && !S.l10.empty()) memcpy(out_log10, S.l10.data(), S.l10.size() * sizeof(double));
@@ -2095,7 +2112,7 @@ extern "C" void accg_phmm_ring_destroy(accg_phmm_ring* r) {
   if (!r) return;
   for (auto& sp : r->slot) {
     RingSlot& S = *sp;
-    if (S.busy) { std::unique_lock<std::mutex> lk(S.mu); S.cv.wait(lk, [&] { return S.done; }); }     // a ticket nobody waited for
+    { std::unique_lock<std::mutex> lk(S.mu); if (S.busy) S.cv.wait(lk, [&] { return S.done; }); }     // a ticket nobody waited for
     { std::lock_guard<std::mutex> lk(S.mu); S.quit = true; }
     S.cv.notify_all();
     if (S.th.joinable()) S.th.join();

@@ -99,32 +99,88 @@ def _wait_for(path, timeout):
         time.sleep(0.01)
 
 
+def run_token():
+    """What marks a rendezvous file as THIS run's: ACCG_RUN_NONCE when whoever starts the ranks sets one (ranks started by different
+    parents -- mpirun / srun daemons, one spawner per GPU -- must: nothing else is common to them), else the launcher's pid and start
+    time, which all children of one launcher compute alike and no earlier run can have had."""
+    n = os.environ.get("ACCG_RUN_NONCE")
+    if n:
+        return "n" + "".join(ch for ch in n if ch.isalnum())[:48]
+    return "p%d_%s" % (os.getppid(), _launcher_token())
+
+
+def _read_tokened(path, token):
+    """The payload of a status / verdict file if it carries this run's token, else None (absent, half-written or another run's)."""
+    try:
+        v = json.load(open(path))
+        return v["v"] if isinstance(v, dict) and v.get("token") == token else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _write_tokened(path, token, payload):
+    with open(path + ".tmp", "w") as f:
+        json.dump({"token": token, "v": payload}, f)
+    os.replace(path + ".tmp", path)
+
+
 def exchange_status(base, phase, rank, world, ok, reason="", timeout=120.0):
-    """Every rank publishes (ok, reason) for `phase` next to the rendezvous file and reads everybody's: the ranks decide TOGETHER
-    whether the RCCL communicator is used, so that no rank sits in a collective the others have given up on.
-    Returns [(ok, reason)] by rank; a rank that does not report within `timeout` counts as failed."""
+    """The ranks decide TOGETHER whether the RCCL communicator is used, so that no rank sits in a collective the others have given up
+    on -- in two phases: every rank publishes (ok, reason) for `phase` next to the rendezvous file, rank 0 reads them all (a rank that
+    does not report within `timeout` counts as failed) and publishes ONE verdict, and every rank, rank 0 included, returns what that
+    verdict says.  Every file carries the run's token (run_token): a file some earlier run left under the same name is ignored, never
+    obeyed.  A rank that does not get a verdict within 2 x timeout returns all-failed for itself -- it cannot have entered a collective
+    the others are in, because nobody enters one before a verdict.  Each rank removes its own status file once it has the verdict;
+    rank 0 removes verdicts of other runs before writing its own (the verdict of this run stays for slower ranks: it is this run's).
+    Returns [(ok, reason)] by rank."""
+    token = run_token()
     mine = "%s.%s.%d" % (base, phase, rank)
-    with open(mine + ".tmp", "w") as f:
-        json.dump([bool(ok), str(reason)], f)
-    os.replace(mine + ".tmp", mine)
-    out = []
-    for r in range(world):
-        p = "%s.%s.%d" % (base, phase, r)
+    verdict = "%s.%s.verdict" % (base, phase)
+    _write_tokened(mine, token, [bool(ok), str(reason)])
+    out = None
+    try:
+        if rank == 0:
+            out, t0 = [None] * world, time.time()
+            while any(o is None for o in out) and time.time() - t0 <= timeout:
+                for r in range(world):
+                    if out[r] is None:
+                        v = _read_tokened("%s.%s.%d" % (base, phase, r), token)
+                        if v is not None:
+                            out[r] = (bool(v[0]), str(v[1]))
+                if any(o is None for o in out):
+                    time.sleep(0.01)
+            out = [o if o is not None else (False, "rank %d did not report within %.0f s" % (r, timeout)) for r, o in enumerate(out)]
+            try:
+                os.unlink(verdict)                       # (another run's, if any; this run's does not exist yet)
+            except OSError:
+                pass
+            _write_tokened(verdict, token, [[bool(o), str(w)] for o, w in out])
+        else:
+            t0 = time.time()
+            while out is None:
+                v = _read_tokened(verdict, token)
+                if v is not None:
+                    out = [(bool(o), str(w)) for o, w in v]
+                elif time.time() - t0 > 2 * timeout:
+                    out = [(False, "no verdict from rank 0 within %.0f s" % (2 * timeout))] * world
+                else:
+                    time.sleep(0.01)
+    finally:
         try:
-            _wait_for(p, timeout)
-            v = json.load(open(p))
-            out.append((bool(v[0]), v[1]))
-        except (TimeoutError, OSError, ValueError) as e:
-            out.append((False, "rank %d did not report (%s)" % (r, e)))
+            os.unlink(mine)
+        except OSError:
+            pass
     return out
 
 
 def _forget_status(base, rank):
+    """Rank 0 removes this run's verdicts at the end (every rank has passed barriers since it read them); status files are gone already."""
     for phase in ("pre", "init"):
-        try:
-            os.unlink("%s.%s.%d" % (base, phase, rank))
-        except OSError:
-            pass
+        for p in ["%s.%s.%d" % (base, phase, rank)] + (["%s.%s.verdict" % (base, phase)] if rank == 0 else []):
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
 
 
 def rccl_preflight(rank, world, base=None):
@@ -197,22 +253,30 @@ class FileComm:
     RCCL, no torch).  Used by the world-2-on-one-GPU test and by `ACCG_BENCH_SHARE_GPU=1 bench.py --gpus N` rehearsals."""
     backend = "file"
     uses_rccl = False
+    _opened = {}          # directory -> communicators opened on it by this process (every rank opens them in the same order)
 
     def __init__(self, ctx, rank, world, directory, timeout=600.0):
         self.ctx, self.rank, self.world, self.dir, self.timeout, self.seq = ctx, rank, world, directory, timeout, 0
         os.makedirs(directory, exist_ok=True)
         # a directory somebody used before (same name, e.g. a fixed ACCG_COMM_FILE): rank 0 removes what is left in it and
         # says so through a `ready` file carrying this launcher's token; nobody reads a counter file before having seen it
-        token = "%d_%s" % (os.getppid(), _launcher_token())        # the ranks of one job are children of one launcher
+        # (the token: run_token() -- ACCG_RUN_NONCE for ranks of different parents; with an explicitly named ACCG_COMM_FILE and no nonce the
+        # ranks may still come from different parents, so the name itself is what they share; and a sequence number per directory, so
+        # that a second communicator opened on the same directory in one job starts clean as well)
+        FileComm._opened[directory] = k = FileComm._opened.get(directory, 0) + 1
+        token = "%s_%d" % (run_token() if (os.environ.get("ACCG_RUN_NONCE") or not os.environ.get("ACCG_COMM_FILE")) else "named", k)
         ready = os.path.join(directory, "ready_%s" % token)
+        self.tag = token
         if rank == 0:
             for f in os.listdir(directory):
-                if f.startswith("ar_") or (f.startswith("ready_") and f != os.path.basename(ready)):
+                if f.startswith("ar_") or f.startswith("ready_"):
                     try:
                         os.unlink(os.path.join(directory, f))
                     except OSError:
                         pass
-            open(ready, "w").close()
+            with open(ready + ".tmp", "w") as f:
+                f.write(token)
+            os.replace(ready + ".tmp", ready)            # (appears whole, after the directory has been cleaned)
         else:
             _wait_for(ready, timeout)
 
@@ -220,13 +284,13 @@ class FileComm:
         if self.ctx is not None:
             self.ctx.synchronize()
         self.seq += 1
-        mine = os.path.join(self.dir, "ar_%d_%d.json" % (self.seq, self.rank))
+        mine = os.path.join(self.dir, "ar_%s_%d_%d.json" % (self.tag, self.seq, self.rank))
         with open(mine + ".tmp", "w") as f:
             json.dump([int(cells), int(pairs), int(kernel_ns), int(rescued), float(wall_s)], f)
         os.replace(mine + ".tmp", mine)
         tot, wall = [0, 0, 0, 0], 0.0
         for r in range(self.world):
-            p = os.path.join(self.dir, "ar_%d_%d.json" % (self.seq, r))
+            p = os.path.join(self.dir, "ar_%s_%d_%d.json" % (self.tag, self.seq, r))
             _wait_for(p, self.timeout)
             v = json.load(open(p))
             tot = [a + b for a, b in zip(tot, v[:4])]
@@ -240,7 +304,7 @@ class FileComm:
         if self.seq:                      # everybody has read file seq-1 of every rank before writing its seq-th: safe to drop
             for q in range(1, self.seq):
                 try:
-                    os.unlink(os.path.join(self.dir, "ar_%d_%d.json" % (q, self.rank)))
+                    os.unlink(os.path.join(self.dir, "ar_%s_%d_%d.json" % (self.tag, q, self.rank)))
                 except OSError:
                     pass
 

@@ -55,7 +55,11 @@ typedef struct {
   uint64_t rescued;      /* pairs recomputed in fp64 (raw < 1e-28f, FalconPairHMM.cpp:84) */
 } accg_counters;
 
-/* ---- context ------------------------------------------------------------------------------- */
+/* ---- context -------------------------------------------------------------------------------
+ * Side effect on the calling thread: the host loops of this library are OpenMP loops, and accg_init (and every ring worker) asks libomp
+ * to let idle team threads sleep after 1 ms instead of spinning for 200 (kmp_set_blocktime(1): spinners eat a container's CPU quota).
+ * That setting is per thread and also governs the caller's own OpenMP regions on that thread.  KMP_BLOCKTIME in the environment wins;
+ * ACCG_KEEP_OMP_BLOCKTIME=1 leaves the application's setting alone; with an OpenMP runtime other than libomp nothing is changed. */
 int accg_init(int device, accg_ctx** out);
 void accg_shutdown(accg_ctx* ctx);
 const char* accg_strerror(int status);
@@ -97,6 +101,10 @@ int accg_phmm_ring_create(accg_ctx* ctx, int slots, accg_phmm_ring** out);
  * pointer and size arrays are copied) MUST STAY UNTOUCHED UNTIL THE TICKET HAS BEEN WAITED FOR; errors of the host half come back from
  * accg_phmm_ring_wait.  Still one caller thread at a time per ring. */
 int accg_phmm_ring_create_threaded(accg_ctx* ctx, int slots, accg_phmm_ring** out);
+/* THREADING CONTRACT of both rings: submit, wait and destroy of one ring are called by ONE thread at a time (the ticket counter and the
+ * slot bookkeeping are the caller's side of the ring; the worker threads of a threaded ring are the library's own).  Callers on several
+ * threads take a ring each -- or accg_phmm_mux_region below, which is made for that.  A ticket's counters carry the device time of its
+ * pass in kernel_ns, like accg_phmm_region's. */
 int accg_phmm_ring_submit(accg_phmm_ring* ring, const void* reads_ser, size_t reads_bytes, const void* haps_ser, size_t haps_bytes,
                           int mode, uint64_t* ticket);
 /* several regions under one ticket (one device batch: its results come back concatenated in region order, like accg_phmm_batch_results) */

@@ -162,3 +162,60 @@ def test_rendezvous_name_carries_a_per_run_nonce(monkeypatch):
     monkeypatch.setenv("MASTER_PORT", "29999")
     name = D.comm_file_default()
     assert name.startswith("/tmp/accg_comm_29999_%d_" % os.getppid()) and name.split("_")[-1] not in ("", "0")
+
+
+def _status_worker_stale(rank, world, base, q, delay):
+    import time
+    time.sleep(delay)            # rank 0 comes late: the others meet the stale files first
+    q.put((rank, D.exchange_status(base, "init", rank, world, True, "", timeout=30)))
+
+
+def test_status_files_of_another_run_are_ignored(tmp_path):
+    """A fixed rendezvous name that an earlier run left its files under (a verdict saying "failed", a status saying "failed"): this
+    run's ranks must neither obey nor count them -- every file carries the run's token, and only rank 0's verdict of THIS run decides."""
+    import json
+    import multiprocessing as mp
+    base = str(tmp_path / "id")
+    for name, payload in ((base + ".init.verdict", [[False, "stale"], [False, "stale"]]), (base + ".init.1", [False, "stale"])):
+        with open(name, "w") as f:
+            json.dump({"token": "p1_of_an_earlier_run", "v": payload}, f)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_status_worker_stale, args=(r, 2, base, q, 1.0 if r == 0 else 0.0)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+    assert all(st == [(True, ""), (True, "")] for _, st in res)
+    assert not os.path.exists(base + ".init.0") and not os.path.exists(base + ".init.1")      # every rank removed its own status
+
+
+def test_status_without_rank0_gives_up_alike(tmp_path, monkeypatch):
+    """No verdict (rank 0 never shows up): the waiting rank reports failure for everybody instead of deciding on its own."""
+    monkeypatch.setenv("ACCG_RUN_NONCE", "t1")
+    res = D.exchange_status(str(tmp_path / "id"), "pre", 1, 2, True, "", timeout=0.2)
+    assert [o for o, _ in res] == [False, False] and "no verdict" in res[0][1]
+
+
+def _file_worker_twice(rank, world, d, q):
+    out = []
+    for k in range(2):                      # two communicators on the same directory in one job
+        c = D.FileComm(None, rank, world, d, timeout=30)
+        out.append(c.allreduce(10 * k + rank, 1, 0, 0, 0.0)[:2])
+        c.close()
+    q.put((rank, out))
+
+
+def test_file_comm_opened_twice_on_one_directory(tmp_path, monkeypatch):
+    import multiprocessing as mp
+    monkeypatch.setenv("ACCG_RUN_NONCE", "twice")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_file_worker_twice, args=(r, 2, str(tmp_path / "c"), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+    assert all(out == [(1, 2), (21, 2)] for _, out in res)

@@ -441,6 +441,7 @@ def test_ring_equals_one_shot(ctx):
                 got.append(ring.wait(t, m))
             for (wr, wl, wc), (gr, gl, gc) in zip(want, got):
                 assert wr.tobytes() == gr.tobytes() and wl.tobytes() == gl.tobytes() and wc.rescued == gc.rescued and wc.cells == gc.cells
+                assert gc.kernel_ns > 0 and wc.kernel_ns > 0          # a ticket carries its device time, like the blocking call
             # several regions under one ticket: the concatenation of their results
             t = ring.submit_many([(a, b) for a, b, _ in ser[:5]])
             gr, gl, gc = ring.wait(t, sum(n for _, _, n in ser[:5]))
