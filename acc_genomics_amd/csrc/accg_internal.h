@@ -70,6 +70,8 @@ struct accg_ctx {
   // set for the duration of a blocking region call (accg_phmm_region, a mux leader's batch): the batch is created for ONE pass whose
   // latency is what counts -- a batch small enough to leave most of the chip idle computes its fp64 values speculatively next to
   // the fp32 sweep instead of behind it (phmm_host.cpp: run_spec)
+  // the job-sizing decision of the PairHMM batch created before on this context (phmm_host.cpp: partition)
+  struct SizingMemo { bool valid = false, pairs = false, dom5 = false; uint64_t budget = 0, regions = 0, med_hap = 0, haps = 0; int K_dom = 0, lpp_dom = 0, nchar = 0; } sizing;
   // a page of host-visible words for device-written flags (made at first use; phmm_host.cpp: the rescue probe of a batch that is run repeatedly)
   uint32_t* h_flags = nullptr;
   uint32_t flag_next = 0;

@@ -773,6 +773,22 @@ void partition(accg_phmm_batch& b) {
     for (size_t ri = 0; ri < b.regions.size(); ri++) jobs1 += (uint64_t)groups[ri].size() * b.regions[ri].n_haps;
     if (jobs1 <= 4ull * (uint64_t)n_cu && !getenv("ACCG_PHMM_STREAM_BUDGET")) { cand.clear(); cand.push_back(1); }
   }
+  // The sizing decision of the batch before, if this one looks like it (a stream of tickets cut from one data set: the same number of
+  // regions within a quarter, the same dominant class and median haplotype length within a tenth): taken as it is, no search.  The
+  // results do not depend on the run length, only the schedule does.  ACCG_PHMM_SIZING_CACHE=0 turns it off.
+  accg_ctx::SizingMemo& memo = b.ctx->sizing;
+  uint64_t med_hap = 0;
+  if (!b.hp.empty()) med_hap = b.hp[b.hp.size() / 2].len;          // (a sample, not the true median: enough to recognise a data set)
+  {
+    static const bool cache_off = [] { const char* e = getenv("ACCG_PHMM_SIZING_CACHE"); return e && e[0] == '0'; }();
+    const uint64_t nr = b.regions.size();
+    const bool alike = memo.valid && !cache_off && cand.size() > 1 && !getenv("ACCG_PHMM_STREAM_BUDGET") && memo.K_dom == K_dom && memo.lpp_dom == lpp_dom &&
+                       memo.dom5 == dom5 && memo.nchar == nchar && nr * 4 >= memo.regions * 3 && nr * 4 <= memo.regions * 5 &&
+                       med_hap * 10 >= memo.med_hap * 9 && med_hap * 10 <= memo.med_hap * 11 && (uint64_t)b.hp.size() * 4 >= memo.haps * 3 &&
+                       (uint64_t)b.hp.size() * 4 <= memo.haps * 5;
+    if (alike) { cand.clear(); cand.push_back(memo.budget); }
+  }
+  const bool from_memo = cand.size() == 1 && memo.valid && cand[0] == memo.budget && b.regions.size() > 0 && !(cand[0] == 1);
   std::vector<double> span1(cand.size(), -1.0), span2(cand.size(), -1.0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(accg::host_threads()) if (cand.size() * b.regions.size() >= 512 && accg::host_threads() > 1)
   for (int ci = 0; ci < (int)cand.size(); ci++) {
@@ -786,6 +802,9 @@ void partition(accg_phmm_batch& b) {
       const double span = pr ? span2[ci] : span1[ci];
       if (span >= 0 && (best_span < 0 || span < best_span)) { best_span = span; best_budget = cand[ci]; best_pairs = pr != 0; }
     }
+  if (from_memo) best_pairs = memo.pairs;
+  else if (cand.size() > 1) { memo.valid = true; memo.budget = best_budget; memo.pairs = best_pairs; memo.K_dom = K_dom; memo.lpp_dom = lpp_dom; memo.dom5 = dom5;
+                              memo.nchar = nchar; memo.regions = b.regions.size(); memo.med_hap = med_hap; memo.haps = b.hp.size(); }
 
   tpc = std::chrono::steady_clock::now();
   struct Job { PhmmWork w, w2; int K, lpp, form; bool striped; int wg; uint64_t cost; uint32_t stream_len; };
@@ -872,7 +891,13 @@ void partition(accg_phmm_batch& b) {
         const SeqRef& h = b.hp[r.hap0 + run.first + k];
         b.streams[w_++] = (uint8_t)nchar;
         const uint8_t* src = b.hp_ptr[r.hap0 + run.first + k];
-        for (uint32_t x = 0; x < h.len; x++) { const uint8_t ch = src[x]; b.streams[w_++] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+        {
+          struct Lut { uint8_t code[256]; Lut() { for (int i = 0; i < 256; i++) code[i] = i == 'A' ? 0 : i == 'C' ? 1 : i == 'G' ? 2 : i == 'T' ? 3 : 4; } };
+          static const Lut lut;
+          uint8_t* dst = b.streams.data() + w_;
+          for (uint32_t x = 0; x < h.len; x++) dst[x] = lut.code[src[x]];
+          w_ += h.len;
+        }
       }
       b.streams[w_++] = (uint8_t)nchar;
       sp += (lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16;
@@ -913,11 +938,26 @@ void partition(accg_phmm_batch& b) {
     // sent the longest jobs, reads of 513 to 1023 bases, to the back of the list)
     static_assert(PHMM_MAX_K < 32, "K takes five bits of the job sort key");
     const uint64_t lane_code = x.lpp >= 64 ? 3 : x.lpp >= 32 ? 2 : x.lpp >= 16 ? 1 : 0;
-    const uint64_t key = ((uint64_t)(x.striped ? 1 : 0) << 63) | ((uint64_t)(mc & 15) << 59) | (lane_code << 53) | ((uint64_t)(x.K & 31) << 48) |
-                         ((uint64_t)(7 - x.form) << 45) | ((uint64_t)(x.wg & 3) << 43) | std::min<uint64_t>(x.cost, (1ull << 43) - 1);
-    order[i] = {~key, (uint32_t)i};
+    // (inside a class K is fixed, so the order by cost is the order by stripes x (stream length + 45): 15 bits of it, clipped -- only
+    // striped reads of several thousand bases against the longest streams reach the clip -- make the key 32 bits, sorted by three
+    // stable counting passes instead of a comparison sort: 5 000 jobs of a 32-region ticket 150 -> 20 us)
+    const uint64_t stripes = x.striped ? (b.rd[x.w.read[0]].len + 1024) / 1024 : 1;
+    const uint32_t len_key = (uint32_t)std::min<uint64_t>(stripes * (uint64_t)(x.stream_len + 45), 32767);
+    const uint32_t key = ((uint32_t)(x.striped ? 1 : 0) << 31) | ((uint32_t)(mc & 15) << 27) | ((uint32_t)lane_code << 25) | ((uint32_t)(x.K & 31) << 20) |
+                         ((uint32_t)(7 - x.form) << 17) | ((uint32_t)(x.wg & 3) << 15) | len_key;
+    order[i] = {(uint64_t)(~key), (uint32_t)i};
   }
-  std::sort(order.begin(), order.end());
+  {
+    std::vector<std::pair<uint64_t, uint32_t>> tmp(order.size());
+    for (int pass = 0; pass < 3; pass++) {
+      const int sh = 11 * pass;
+      uint32_t cnt[2049] = {0};
+      for (const auto& o : order) cnt[((o.first >> sh) & 2047u) + 1]++;
+      for (int q = 0; q < 2048; q++) cnt[q + 1] += cnt[q];
+      for (const auto& o : order) tmp[cnt[(o.first >> sh) & 2047u]++] = o;
+      order.swap(tmp);
+    }
+  }
   // (the jobs are read through the sorted index: copying them into order first cost as much as the sort)
   b.work.clear();
   b.work.reserve(jobs.size() * 2);
