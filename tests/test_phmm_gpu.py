@@ -420,6 +420,26 @@ def test_rescue_launch_shapes_agree(ctx, monkeypatch):
             assert len({got[(form5, wg, merge)] for wg in ("1", "2") for merge in ("0", "1")}) == 1
 
 
+def test_one_shot_shapes_change_nothing(ctx, monkeypatch):
+    """A small one-shot batch runs other shapes than a device-resident one -- sixteen lanes per read in the sweep, the speculative fp64
+    pass next to the sweep, results by a copy kernel -- and a pair's bits must not depend on any of that: the blocking call per region
+    (speculation on and off) against one device-resident batch of the same regions."""
+    rng = synth.rng_for(351)
+    regs = [synth.make_region(rng, 40, 6, (30, 127), (60, 300), unrelated_frac=0.4, n_frac=0.01),
+            synth.make_region(rng, 17, 3, (90, 150), (100, 400), unrelated_frac=0.5),
+            synth.make_region(rng, 5, 2, (20, 40), (50, 90), unrelated_frac=0.6)]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
+    with A.PhmmBatch(ctx, [(a, b) for a, b, _ in ser]) as bt:
+        bt.run(A.ACCG_PHMM_FAST)
+        raw, l10, cnt = bt.results()
+        assert cnt.rescued > 50
+    for spec in ("1", "0"):
+        monkeypatch.setenv("ACCG_PHMM_SPEC", spec)
+        one = [ctx.phmm_region(a, b, n) for a, b, n in ser]
+        assert b"".join(r.tobytes() for r, _, _ in one) == raw.tobytes() and b"".join(l.tobytes() for _, l, _ in one) == l10.tobytes()
+        assert sum(c.rescued for _, _, c in one) == cnt.rescued
+
+
 def test_ring_equals_one_shot(ctx):
     """Regions in flight (accg_phmm_ring_*): the same bits as the blocking call, whatever the number of slots; a slot that has not
     been waited for refuses the next submit."""
