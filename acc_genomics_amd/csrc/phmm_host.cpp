@@ -415,6 +415,8 @@ struct accg_phmm_batch {
   // ones: from its second pass on the planner reports "something flagged" into a host-visible word, an event marks the end of that pass's
   // tail, and once the host sees the event done and the word still 0 it stops queueing the planner and the (empty) fp64 launches for
   // this batch in this mode -- two dependent launches and their gaps per pass (configs[1]: some 20 us of 275).
+  std::vector<hipEvent_t> step_ev;   // accg_phmm_batch_steps_*: [0], [1] around all passes, then a pair per pass around its sweep launches
+  int steps_queued = 0;
   int rescue_known[2] = {0, 0};      // per mode: 0 not known yet, 1 never rescues, 2 rescues
   int probe_runs[2] = {0, 0};
   hipEvent_t ev_probe[2] = {nullptr, nullptr};
@@ -1662,30 +1664,53 @@ extern "C" int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int
 // pair of events around its fp32 sweep launches on the stream they are launched on: the dominant kernel timed INSIDE the step,
 // in the clock state the steps run in.  kernel_ms = mean time between those events (one kernel for a single-class batch, the
 // forked classes otherwise), step_ms = mean time of a whole pass.
-extern "C" int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float* kernel_ms, float* step_ms) {
-  if (!b || !kernel_ms || !step_ms || iters <= 0 || iters > 4096) return ACCG_ERR_BAD_ARG;
+// In three parts, so that a caller who brackets the passes with a clock of its own (bench.py's timed region) has nothing but the passes
+// inside the bracket: _reserve makes the events (before), _run queues `iters` passes with their events and returns without waiting,
+// _times reads the events (after the caller's own wait).
+extern "C" int accg_phmm_batch_steps_reserve(accg_phmm_batch* b, int iters) {
+  if (!b || iters <= 0 || iters > 4096) return ACCG_ERR_BAD_ARG;
   ACCG_HIP(hipSetDevice(b->ctx->device));
+  while (b->step_ev.size() < 2 * (size_t)iters + 2) {
+    hipEvent_t e = nullptr;
+    ACCG_HIP(hipEventCreate(&e));
+    b->step_ev.push_back(e);
+  }
+  return ACCG_OK;
+}
+extern "C" int accg_phmm_batch_steps_run(accg_phmm_batch* b, int mode, int iters) {
+  int st = accg_phmm_batch_steps_reserve(b, iters);
+  if (st != ACCG_OK) return st;
   accg_ctx* c = b->ctx;
-  std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
-  struct Drop { std::vector<hipEvent_t>& e; ~Drop() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); } } drop{ev};
-  for (hipEvent_t& e : ev) ACCG_HIP(hipEventCreate(&e));
-  int st;
+  std::vector<hipEvent_t>& ev = b->step_ev;
   if ((st = join_tail(b)) != ACCG_OK) return st;
-  ACCG_HIP(hipEventRecord(c->ev0, c->stream));
+  ACCG_HIP(hipEventRecord(ev[0], c->stream));
   for (int i = 0; i < iters; i++) {
-    if ((st = run_direct(b, mode, ev[2 * i], ev[2 * i + 1])) != ACCG_OK) return st;
+    if ((st = run_direct(b, mode, ev[2 + 2 * i], ev[3 + 2 * i])) != ACCG_OK) return st;
   }
   if ((st = join_tail(b)) != ACCG_OK) return st;
-  ACCG_HIP(hipEventRecord(c->ev1, c->stream));
-  ACCG_HIP(hipEventSynchronize(c->ev1));
+  ACCG_HIP(hipEventRecord(ev[1], c->stream));
+  b->steps_queued = iters;
+  return ACCG_OK;
+}
+extern "C" int accg_phmm_batch_steps_times(accg_phmm_batch* b, float* kernel_ms, float* step_ms) {
+  if (!b || !kernel_ms || !step_ms || b->steps_queued <= 0) return ACCG_ERR_BAD_ARG;
+  ACCG_HIP(hipSetDevice(b->ctx->device));
+  const int iters = b->steps_queued;
+  std::vector<hipEvent_t>& ev = b->step_ev;
+  ACCG_HIP(hipEventSynchronize(ev[1]));
   float ms = 0;
-  ACCG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  ACCG_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
   *step_ms = ms / iters;
   double sum = 0;
-  for (int i = 0; i < iters; i++) { float k = 0; ACCG_HIP(hipEventElapsedTime(&k, ev[2 * i], ev[2 * i + 1])); sum += k; }
+  for (int i = 0; i < iters; i++) { float k = 0; ACCG_HIP(hipEventElapsedTime(&k, ev[2 + 2 * i], ev[3 + 2 * i])); sum += k; }
   *kernel_ms = (float)(sum / iters);
   b->last_kernel_ns = (uint64_t)((double)ms / iters * 1e6);
   return ACCG_OK;
+}
+extern "C" int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float* kernel_ms, float* step_ms) {
+  if (!b || !kernel_ms || !step_ms || iters <= 0 || iters > 4096) return ACCG_ERR_BAD_ARG;
+  const int st = accg_phmm_batch_steps_run(b, mode, iters);
+  return st != ACCG_OK ? st : accg_phmm_batch_steps_times(b, kernel_ms, step_ms);
 }
 // The shader clock the device held while the first wavefront of the last sweep launch ran its job (s_memtime ticks over 100 MHz
 // wall-clock ticks, both taken by that wavefront): the clock UNDER the kernel, not that of an idle or lightly loaded card.
@@ -1840,6 +1865,7 @@ extern "C" void accg_phmm_batch_destroy(accg_phmm_batch* b) {
   if (b->ctx->tail && (b->tail_pending || b->alt.tail_pending || b->runs)) hipStreamSynchronize(b->ctx->tail);
   for (hipGraphExec_t& g : b->graph_exec) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   for (hipEvent_t& e : b->ev_probe) if (e) { hipEventDestroy(e); e = nullptr; }
+  for (hipEvent_t e : b->step_ev) if (e) hipEventDestroy(e);
   if (b->ev_sweep) hipEventDestroy(b->ev_sweep);
   if (b->tail_done) hipEventDestroy(b->tail_done);
   if (b->alt.tail_done) hipEventDestroy(b->alt.tail_done);

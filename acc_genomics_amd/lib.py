@@ -68,6 +68,9 @@ def load():
     L.accg_phmm_batch_results_f64.argtypes = [vp, vp]
     L.accg_phmm_batch_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.accg_phmm_batch_time2.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.accg_phmm_batch_steps_reserve.argtypes = [vp, C.c_int]
+    L.accg_phmm_batch_steps_run.argtypes = [vp, C.c_int, C.c_int]
+    L.accg_phmm_batch_steps_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.accg_phmm_batch_time_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.accg_phmm_batch_time_in_step.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.accg_ctx_clock_ghz.argtypes = [vp, C.POINTER(C.c_float)]
@@ -273,6 +276,19 @@ class PhmmBatch:
         """(kernel_ms, step_ms): the fp32 sweep timed with HIP events inside `iters` whole back-to-back passes, and the pass itself."""
         k, s = C.c_float(), C.c_float()
         _check(self.L.accg_phmm_batch_time_in_step(self.h, mode, iters, C.byref(k), C.byref(s)))
+        return k.value, s.value
+
+    def steps_reserve(self, iters):
+        _check(self.L.accg_phmm_batch_steps_reserve(self.h, iters))
+
+    def steps_run(self, mode, iters):
+        """Queues `iters` whole passes, each with events around its sweep launch; does not wait."""
+        _check(self.L.accg_phmm_batch_steps_run(self.h, mode, iters))
+
+    def steps_times(self):
+        """(kernel_ms, step_ms) of the passes steps_run queued (waits for them)."""
+        k, s = C.c_float(), C.c_float()
+        _check(self.L.accg_phmm_batch_steps_times(self.h, C.byref(k), C.byref(s)))
         return k.value, s.value
 
     def time_prepare(self, iters=20):

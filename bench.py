@@ -769,15 +769,18 @@ def main():
     batch = A.PhmmBatch(ctx, [(synth.serialize_reads(reads), synth.serialize_haps(haps))])
     for _ in range(args.warmup):
         batch.run(mode)
+    if args.steps <= 4096:
+        batch.steps_reserve(args.steps)
     ctx.synchronize()
     comm.barrier()
-    # The K timed steps ARE instrumented passes: accg_phmm_batch_time_in_step queues exactly `steps` whole passes (the launches of
+    # The K timed steps ARE instrumented passes: accg_phmm_batch_steps_run queues exactly `steps` whole passes (the launches of
     # accg_phmm_batch_run, in the same order) with a pair of HIP events around each pass's fp32 sweep launch on the stream it is launched
     # on, so kernel_ms is the dominant kernel's mean duration in the very steps ms_per_step is taken over (same clock state: a card
     # that has just left idle runs its first steps 10 % slower than its hundredth, and a kernel time taken later would not be theirs).
+    # (the events are made before the bracket and read after it: inside it are the launches of the K passes and the wait for them)
     t0 = time.perf_counter()
     if args.steps <= 4096:
-        k_ms, step_ev_ms = batch.time_in_step(mode, iters=args.steps)
+        batch.steps_run(mode, args.steps)
     else:
         for _ in range(args.steps):
             batch.run(mode)
@@ -785,8 +788,7 @@ def main():
     t1 = time.perf_counter()
     comm.barrier()
     elapsed = t1 - t0
-    if args.steps > 4096:
-        k_ms, step_ev_ms = batch.time_in_step(mode, iters=1000)
+    k_ms, step_ev_ms = batch.steps_times() if args.steps <= 4096 else batch.time_in_step(mode, iters=1000)
     clock_ghz = batch.clock_ghz()        # measured by the sweep kernel itself (its first wavefront: shader-clock over wall-clock ticks)
     clock_probe_ghz = ctx.clock_ghz()    # ... and what a light 0.3 ms fp32 kernel holds right behind it
     raw, _, cnt = batch.results(want_log10=False)
@@ -854,7 +856,7 @@ def main():
                 "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
                 "traffic": tj.get("hbm_bytes_per_launch"), "kernel": PHMM_KERNEL_NAME, "kernel_ms": k_ms,
                 "kernel_ms_how": "mean over the %d timed steps themselves: HIP events around the fp32 sweep launch inside each pass, on the stream it is "
-                                 "launched on (accg_phmm_batch_time_in_step); by those events the passes took %.4f ms each" % (args.steps, step_ev_ms),
+                                 "launched on (accg_phmm_batch_steps_run / _times); by those events the passes took %.4f ms each" % (args.steps, step_ev_ms),
                 "algorithmic_bytes_per_launch": algo,
                 # the roofs that bind (the kernel is fp32-VALU-issue bound, 6.6e-4 B/cell keeps HBM idle)
                 "binding": "fp32 VALU issue",

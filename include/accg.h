@@ -138,6 +138,12 @@ int accg_phmm_batch_time2(accg_phmm_batch* b, int mode, int what, int warmup, in
 /* `iters` whole passes back to back with HIP events around each pass's fp32 sweep launches, on the stream they are launched on:
  * kernel_ms = mean of the dominant kernel measured INSIDE the step, step_ms = mean whole pass (same run, same clock state) */
 int accg_phmm_batch_time_in_step(accg_phmm_batch* b, int mode, int iters, float* kernel_ms, float* step_ms);
+/* The same in three parts, for a caller that brackets the passes with a clock of its own and wants nothing but the passes inside the
+ * bracket: _reserve makes the events (before the bracket), _run queues `iters` passes with their events and returns without waiting,
+ * _times reads them (after the caller's own accg_ctx_synchronize). */
+int accg_phmm_batch_steps_reserve(accg_phmm_batch* b, int iters);
+int accg_phmm_batch_steps_run(accg_phmm_batch* b, int mode, int iters);
+int accg_phmm_batch_steps_times(accg_phmm_batch* b, float* kernel_ms, float* step_ms);
 /* The per-row coefficient records of the fast sweep are written ONCE, at batch creation (a pure function of the reads, like the haplotype
  * streams): a pass over a device-resident batch does not rewrite them.  This times the kernel that writes them, mean of `iters` launches. */
 int accg_phmm_batch_time_prepare(accg_phmm_batch* b, int iters, float* ms_per_run);
