@@ -12,9 +12,6 @@
 #include <string>
 #include <vector>
 
-struct accg_ctx;
-struct accg_phmm_batch;
-
 namespace task_host {
 class Task {
  public:

@@ -85,3 +85,41 @@ def test_mux_reports_errors_per_region(driver):
                 assert res[i][0] == -5                      # ACCG_ERR_BAD_BASE
             else:
                 assert res[i][0] == 0 and res[i][1].tobytes() == ctx.phmm_region(a, b, m)[0].tobytes()
+
+
+@pytest.mark.gpu
+def test_mux_strict_mode_and_large_regions():
+    """Through the mux: the strict arithmetic mode, and regions too large for the small-batch transfers (results over 2 MB go by
+    hipMemcpyAsync and are timed by events) next to small ones -- the bits of accg_phmm_region every time."""
+    import ctypes as C
+    import threading
+    import acc_genomics_amd as A
+    from acc_genomics_amd import synth
+    L = A.load()
+    rng = synth.rng_for(4300)
+    regs = [synth.make_region(rng, 1024, 200, (60, 90), (80, 120), unrelated_frac=0.05),      # 204800 pairs
+            synth.make_region(rng, 30, 4, (20, 150), (100, 300), unrelated_frac=0.3),
+            synth.make_region(rng, 300, 40, (100, 101), (200, 260), unrelated_frac=0.1),
+            synth.make_region(rng, 3, 1, (5, 14), (30, 40))]
+    ser = [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs]
+    for mode in (A.ACCG_PHMM_FAST, A.ACCG_PHMM_STRICT):
+        with A.Context(0) as ctx:
+            want = [ctx.phmm_region(a, b, m, mode) for a, b, m in ser]
+        mux = C.c_void_p()
+        assert L.accg_phmm_mux_create(0, 2, 64, C.byref(mux)) == 0
+        got = [None] * len(ser)
+
+        def call(i):
+            a, b, m = ser[i]
+            raw, l10, cnt = np.zeros(m, np.float32), np.zeros(m, np.float64), A.lib.Counters()
+            st = L.accg_phmm_mux_region(mux, a, len(a), b, len(b), mode, raw.ctypes.data, l10.ctypes.data, C.byref(cnt))
+            got[i] = (st, raw, l10, cnt.rescued, cnt.cells, cnt.kernel_ns)
+
+        for rep in range(2):
+            th = [threading.Thread(target=call, args=(i,)) for i in range(len(ser))]
+            for t in th: t.start()
+            for t in th: t.join()
+            for (wr, wl, wc), (st, gr, gl, resc, cells, kns) in zip(want, got):
+                assert st == 0 and gr.tobytes() == wr.tobytes() and gl.tobytes() == wl.tobytes()
+                assert resc == wc.rescued and cells == wc.cells and kns > 0
+        L.accg_phmm_mux_destroy(mux)
