@@ -604,8 +604,9 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
                                 "what": "accg_phmm_ring_submit / _wait, four regions in flight, one caller thread; " + what}
         out["c3_slice_one_batch"] = {"regions": n_c3, "ms_total": t_batch * 1e3, "value": c3_cells / t_batch / 1e9, "unit": "GCUPS",
                                      "what": "all regions handed over at once: accg_phmm_batch_create + _run + _results; " + what}
-        # a longer stream in tickets of 32 regions, three tickets in flight: the host half of ticket i + 1 behind the device half of ticket i
-        n_st, G = 4 * n_c3, 32
+        # a longer stream in tickets of 64 regions, three tickets in flight: the host half of ticket i + 1 behind the device half of ticket i
+        # (round 3 cut tickets of 32: the device's own rate on a batch of 32 regions, 4.4 TCUPS, then caps the stream; 64: 4.8)
+        n_st, G = 8 * n_c3, 64
         regs2 = regs + [c3_region(k) for k in range(n_c3, n_st)]
         ser2 = ser + [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs2[n_c3:]]
         st_cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs2)
@@ -626,7 +627,7 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
                             "unit": "GCUPS", "what": "accg_phmm_ring_submit_many / _wait over the first %d configs[3] regions, one caller thread, median of 3 passes" % n_st}
         # a stream twice as long through a threaded ring: the host half of every ticket (and the end of its device half: download, log10)
         # on the worker thread of its slot, eight tickets in flight
-        n_th, S_th = 8 * n_c3, 8
+        n_th, S_th = 16 * n_c3, 8
         regs3 = regs2 + [c3_region(k) for k in range(n_st, n_th)]
         ser3 = ser2 + [(synth.serialize_reads(r), synth.serialize_haps(h), len(r) * len(h)) for r, h in regs3[n_st:]]
         th_cells = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs3)
@@ -656,7 +657,7 @@ def bench_e2e(ctx, reads, haps, n_c3, mode):
             import bench_dropin as BD
             LD = BD.load()
             n_dr = 4 * n_c3
-            cells_dr = st_cells if n_dr == n_st else None
+            cells_dr = sum(sum(len(x["b"]) for x in r) * sum(len(x) for x in h) for r, h in regs2[:n_dr])
             dr = {"regions": n_dr, "what": "one configs[3] region (128 reads x 16 haplotypes) per blocking call over the first %d regions, T native caller "
                                            "threads, best of 3 passes after a warm-up pass; wire blobs in host memory in, results in host memory out" % n_dr,
                   "entry_points": {}}
@@ -922,7 +923,9 @@ def main():
             "dropin_mux_region_gcups_1_thread": dig(e2e, "dropin", "entry_points", "accg_phmm_mux_region", "threads_1", "value"),
             "dropin_mux_region_gcups_16_threads": dig(e2e, "dropin", "entry_points", "accg_phmm_mux_region", "threads_16", "value"),
             "dropin_region_ctx_per_thread_gcups_16_threads": dig(e2e, "dropin", "entry_points", "accg_phmm_region_ctx_per_thread", "threads_16", "value"),
-            "e2e_c3_stream_threaded_gcups": dig(e2e, "c3_stream_threaded", "value"),
+            "e2e_c3_stream_gcups": dig(e2e, "c3_stream", "value"), "e2e_c3_stream_threaded_gcups": dig(e2e, "c3_stream_threaded", "value"),
+            "e2e_c3_stream_frac_of_device_resident": (max(dig(e2e, "c3_stream", "value") or 0.0, dig(e2e, "c3_stream_threaded", "value") or 0.0) / dig(c3, "value"))
+                                                     if dig(c3, "value") and dig(e2e, "c3_stream", "value") else None,
             "c3_gcups": dig(c3, "value"), "c3_proxy_speedup_2": dig(c3, "proxy", "n_2", "predicted_speedup"),
             "c3_proxy_speedup_4": dig(c3, "proxy", "n_4", "predicted_speedup"), "c3_proxy_speedup_8": dig(c3, "proxy", "n_8", "predicted_speedup"),
             "sw_gcups": dig(sw, "value"), "sw_with_cigar_gcups": dig(sw, "with_cigar", "value"),
