@@ -23,6 +23,10 @@ struct SwArgs {
   // backtrace mode only:
   uint4* bt;                 // decision bit planes, one uint4 per (step, lane): see sw_kernel.hip
   uint64_t bt_item_stride;   // uint4 elements per wavefront job
+  // Record layout.  0: one uint4 of four bit planes per (step, lane), formed arithmetically (every shape).  1 (16 lanes per pair, packed
+  // int16): the decisions as 64-bit LANE MASKS straight out of v_cmp_lt_i16_sdwa -- per (step t, row k) eight masks of 8 bytes,
+  // [half][x, y, z, w], bit = lane of the wavefront -- sent to memory by scalar stores: at (t * K + k) * 4 uint4 of the job's block.
+  int bt_masks;
   int32_t* cig_n;            // per pair: number of elements, or -(needed) when max_el was too small, or -1 (no alignment)
   int32_t* cig_off;          // per pair: alignment_offset
   int32_t* cig_el;           // per pair: max_el x {length, state} (device-side slots, backtrace order)
@@ -46,5 +50,6 @@ hipError_t sw_trace_launch(int K, int lpp, bool pack16, bool lane_is_alt, const 
 size_t sw_lds_bytes(int sweep_cap);
 __host__ __device__ inline int sw_group_stride(int sweep_cap) { return ((sweep_cap + 1 + 15) / 32) * 32 + 16; }   // >= cap + 1, = 16 mod 32
 inline uint64_t sw_bt_item_uint4(int sweep_cap, int lpp) { return (uint64_t)64 * (sweep_cap + lpp); }
+inline uint64_t sw_bt_item_uint4_masks(int sweep_cap, int lpp, int K) { return (uint64_t)4 * K * (sweep_cap + lpp + 1); }
 
 }  // namespace accg

@@ -190,9 +190,13 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
     const uint64_t by_cut = std::max<uint64_t>(4096, (l.n_work + SW_BT_MIN_SLICES - 1) / SW_BT_MIN_SLICES);
     return std::max<uint64_t>(1, std::min<uint64_t>(l.n_work, std::min(by_mem, by_cut)));
   };
+  // the record's layout per launch: lane masks through scalar stores where the shape has them (sw_dev.h: SwArgs::bt_masks; ACCG_SW_MASKS=0: never)
+  static const bool masks_off = [] { const char* e = getenv("ACCG_SW_MASKS"); return e && e[0] == '0'; }();
+  auto use_masks = [&](const SwLaunch& l) { return !masks_off && l.pack16 && l.lpp == 16; };
+  auto item_uint4 = [&](const SwLaunch& l) { return use_masks(l) ? sw_bt_item_uint4_masks(l.sweep_cap, l.lpp, l.K) : sw_bt_item_uint4(l.sweep_cap, l.lpp); };
   uint64_t half = 0;
   for (const SwLaunch& l : b->launches) {
-    const uint64_t per = sw_bt_item_uint4(l.sweep_cap, l.lpp) * sizeof(uint4);
+    const uint64_t per = item_uint4(l) * sizeof(uint4);
     half = std::max(half, slice_items(l, per) * per);
   }
   half = (half + 255) & ~(uint64_t)255;
@@ -215,7 +219,8 @@ extern "C" int accg_sw_batch_run_cigar(accg_sw_batch* b, int max_el) {
   bool used[2] = {false, false};
   uint32_t k = 0;
   for (const SwLaunch& l : b->launches) {
-    a.bt_item_stride = sw_bt_item_uint4(l.sweep_cap, l.lpp);
+    a.bt_item_stride = item_uint4(l);
+    a.bt_masks = use_masks(l) ? 1 : 0;
     const uint64_t per = a.bt_item_stride * sizeof(uint4);
     const uint32_t slice = (uint32_t)slice_items(l, per);
     for (uint32_t off = 0; off < l.n_work; off += slice, k++) {

@@ -122,8 +122,13 @@ __device__ __forceinline__ unsigned long long group_max_u64(unsigned long long v
 //   z: cell is NOT diagonal            (diag >= down && diag >= right fails, :1798)
 //   w: DOWN wins over RIGHT            (right >= down fails, :1803)
 // With the planes, btrack's +-k (:1805-1809) is the run length of not-opened cells walked by sw_trace.
-template <int K, int LPP, bool P16, bool LANE_IS_ALT, bool BT>
+// MASK (BT, packed int16, 16 lanes per pair): the record as lane masks through scalar stores (SwArgs::bt_masks).  What it saves: the
+// arithmetic extraction is a half-rate packed subtract and two full-rate operations per plane and row (as much issue time as the fill
+// itself); a v_cmp_lt_i16_sdwa per plane, row and half costs 0.87 of a packed operation and the scalar stores ride the
+// scalar-memory pipe for free (tools/ubench_sstore.hip, profiles/r04_ubench_sstore.txt).
+template <int K, int LPP, bool P16, bool LANE_IS_ALT, bool BT, bool MASK = false>
 __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, uint32_t bt_first, int sweep_cap) {
+  static_assert(!MASK || (BT && P16 && LPP == 16), "lane-mask record: packed int16, 16 lanes per pair");
   typedef Val<P16> VT;
   typedef typename VT::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,6 +212,8 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
 
   // ---- sweep ---------------------------------------------------------------------------------------
   unsigned dbg_acc = 0;
+  // (MASK: the job's block of the record; a step's K x 64 bytes at t * K * 64 -- kept in SGPRs, the stores are scalar)
+  const uint64_t rec_job = MASK ? (uint64_t)(a.bt + (uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride) : 0ull;
   for (int t = 1; t <= t_end; t++) {
     // hand-off from the lane on the left (all lanes, also the switched-off ones: their registers are frozen)
     d_in = h_in;
@@ -219,6 +226,7 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
       T hup = h_in, hdiag = d_in, f = f_in;
       T fo = VT::adds(h_in, opn_s);                                      // H of the position above + w_open
       unsigned pf = 0, pg = 0, pn = 0, pd = 0;
+      const uint64_t rec_step = MASK ? rec_job + (uint64_t)t * (uint64_t)(K * 64) : 0ull;
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const T hold = Hp[k];
@@ -229,7 +237,31 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
         const T dg = VT::adds(hdiag, VT::score(ch[k], c, wm[k], wd[k]));
         const T m = VT::mx(G[k], f);
         const T hn = VT::mx(dg, m);
-        if (BT) {
+        if constexpr (MASK) {
+          // eight compares into fixed SGPR pairs, four 16-byte scalar stores: [half][x, y, z, w].  The wait in front: the stores of the
+          // row before have read their SGPRs (measured free: the scalar-memory pipe is idle otherwise); the s_nop: VALU-written
+          // SGPRs read by a scalar-memory instruction (inline assembly gets no hazard padding from the compiler).
+          const int wa = VT::bits(LANE_IS_ALT ? f : G[k]), wb = VT::bits(LANE_IS_ALT ? G[k] : f);      // right < down
+          asm volatile(
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "v_cmp_lt_i16_sdwa s[40:41], %0, %1 src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+              "v_cmp_lt_i16_sdwa s[42:43], %2, %3 src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+              "v_cmp_lt_i16_sdwa s[44:45], %4, %5 src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+              "v_cmp_lt_i16_sdwa s[46:47], %6, %7 src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+              "v_cmp_lt_i16_sdwa s[48:49], %0, %1 src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+              "v_cmp_lt_i16_sdwa s[50:51], %2, %3 src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+              "v_cmp_lt_i16_sdwa s[52:53], %4, %5 src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+              "v_cmp_lt_i16_sdwa s[54:55], %6, %7 src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+              "s_nop 4\n\t"
+              "s_store_dwordx4 s[40:43], %8, %9\n\t"
+              "s_store_dwordx4 s[44:47], %8, %10\n\t"
+              "s_store_dwordx4 s[48:51], %8, %11\n\t"
+              "s_store_dwordx4 s[52:55], %8, %12\n\t"
+              :
+              : "v"(VT::bits(fe)), "v"(VT::bits(fo)), "v"(VT::bits(ge)), "v"(VT::bits(go)), "v"(VT::bits(dg)), "v"(VT::bits(m)), "v"(wa), "v"(wb),
+                "s"(rec_step), "n"(k * 64), "n"(k * 64 + 16), "n"(k * 64 + 32), "n"(k * 64 + 48)
+              : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "memory");
+        } else if (BT) {
           pf = VT::push_lt(pf, fe, fo);
           pg = VT::push_lt(pg, ge, go);
           pn = VT::push_lt(pn, dg, m);
@@ -239,13 +271,14 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
         fo = VT::adds(hn, opn_s); Ho[k] = fo;
       }
       h_last = hup; f_last = f;
-      if (BT) {
+      if (BT && !MASK) {
         if (a.bt) a.bt[(uint64_t)(blockIdx.x + work_base - bt_first) * a.bt_item_stride + ((uint64_t)g * (sweep_cap + LPP) + t) * LPP + l] = make_uint4(pf, pg, pn, pd);
         else dbg_acc ^= pf ^ (pg * 3u) ^ (pn * 5u) ^ (pd * 7u);       // measurement aid (ACCG_SW_BT_DEBUG=2, tools/exp_sw_bt.py): planes formed, nothing stored
       }
       if (l == LPP - 1) my_log[i] = VT::bits(hup);
     }
   }
+  if constexpr (MASK) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    // the scalar cache's dirty lines, before the backtrace kernel reads them
   __syncthreads();
   if (BT && !a.bt && dbg_acc == 0x12345u) a.score[0] = (int)dbg_acc;
 
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
 // Restates calculateCigarOneBatch (FalconSW_AVX.cpp:2341-2417) on top of the bit planes: the walk, the
 // strategy-specific tail, alignment_offset and the final reversal.
 template <bool LANE_IS_ALT>
-__global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap) {
+__global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap, int masks) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t wi = tid >> 3, slot = tid & 7;
   const uint32_t pair = wi < n_work ? a.work[work_base + wi].pair[slot] : SW_NO_PAIR;
@@ -324,7 +357,8 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   const int refLen = a.ref_len[pair], altLen = a.alt_len[pair], strat = a.strategy[pair];
   const int nl = LANE_IS_ALT ? altLen : refLen;
   const int pad = LPP * K - nl;
-  const uint4* bt = a.bt + (uint64_t)(work_base + wi - bt_first) * a.bt_item_stride + (uint64_t)g * (sweep_cap + LPP) * LPP;
+  const uint4* bt = a.bt + (uint64_t)(work_base + wi - bt_first) * a.bt_item_stride + (masks ? 0ull : (uint64_t)g * (sweep_cap + LPP) * LPP);
+  const int lane_bit0 = g * LPP;              // (mask layout: this pair's lanes in the wavefront's masks)
   // planes: 0 lane-direction gap opened, 1 sweep-direction gap opened; "right" (insertion) runs along the alternate
   const int P_HOPEN = LANE_IS_ALT ? 0 : 1, P_VOPEN = LANE_IS_ALT ? 1 : 0;
   int p1 = a.p1[pair], p2 = a.p2[pair];
@@ -344,11 +378,20 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   // diagonal, so the record entries of the next eight diagonal cells -- and, inside a gap, of the next eight cells along the
   // gap -- are fetched together and then examined in order: one memory latency per eight cells instead of one per cell.
   constexpr int LOOK = 8;
-  auto entry = [&](int i, int j, int& shift) -> const uint4* {
+  // the four decision bits of cell (i, j) as planes {x, y, z, w} with the cell's bit at `shift`
+  // (gap_bits: the caller looks at x / y only -- inside a gap run -- else at z / w only: one 16-byte load per cell in the mask layout too)
+  auto entry = [&](int i, int j, int& shift, bool gap_bits) -> uint4 {
     const int sidx = LANE_IS_ALT ? i : j, pos = LANE_IS_ALT ? j : i;
     const int flat = pos - 1 + pad, l = flat / K, k = flat - l * K;
+    if (masks) {      // [half][x, y, z, w] lane masks of (step, row): this cell's lane bit of each, as planes with the bit at 0
+      const uint4 m = bt[((uint64_t)(sidx + l) * K + k) * 4 + half * 2 + (gap_bits ? 0 : 1)];
+      const int bit = lane_bit0 + l;
+      const unsigned b0 = (unsigned)((((unsigned long long)m.y << 32 | m.x) >> bit) & 1ull), b1 = (unsigned)((((unsigned long long)m.w << 32 | m.z) >> bit) & 1ull);
+      shift = 0;
+      return gap_bits ? make_uint4(b0, b1, 0u, 0u) : make_uint4(0u, 0u, b0, b1);
+    }
     shift = p16 ? Val<true>::plane_bit(K, k, half) : Val<false>::plane_bit(K, k, half);
-    return bt + (uint64_t)(sidx + l) * LPP + l;
+    return bt[(uint64_t)(sidx + l) * LPP + l];
   };
   do {
     // ---- run of diagonal cells starting at (p1, p2)
@@ -357,7 +400,7 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
 #pragma unroll
     for (int d = 0; d < LOOK; d++) {
       sh[d] = 0; e[d] = make_uint4(0, 0, 0, 0);
-      if (d < nv) e[d] = *entry(p1 - d, p2 - d, sh[d]);
+      if (d < nv) e[d] = entry(p1 - d, p2 - d, sh[d], false);
     }
     int d = 0;
 #pragma unroll
@@ -385,7 +428,7 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
 #pragma unroll
       for (int q = 0; q < LOOK; q++) {
         gs[q] = 0; ge[q] = make_uint4(0, 0, 0, 0);
-        if (q < gn) ge[q] = down ? *entry(r - q, p2, gs[q]) : *entry(p1, r - q, gs[q]);
+        if (q < gn) ge[q] = down ? entry(r - q, p2, gs[q], true) : entry(p1, r - q, gs[q], true);
       }
       int t = 0;
 #pragma unroll
@@ -433,6 +476,18 @@ hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_f
   if (n == 0) return hipSuccess;
   const size_t lds = sw_lds_bytes(cap);
 #define ACCG_CASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, LPP, P16, LIA, BT>), dim3(n), dim3(64), lds, st, a, wb, bt_first, cap); break;
+  if constexpr (LPP == 16 && P16 && BT) {
+    if (a.bt_masks && a.bt) {
+#define ACCG_MCASE(KK) case KK: hipLaunchKernelGGL((sw_kernel<KK, 16, true, LIA, true, true>), dim3(n), dim3(64), lds, st, a, wb, bt_first, cap); break;
+      switch (K) {
+        ACCG_MCASE(1) ACCG_MCASE(2) ACCG_MCASE(3) ACCG_MCASE(4) ACCG_MCASE(5) ACCG_MCASE(6) ACCG_MCASE(7) ACCG_MCASE(8)
+        ACCG_MCASE(9) ACCG_MCASE(10) ACCG_MCASE(11) ACCG_MCASE(12) ACCG_MCASE(13) ACCG_MCASE(14) ACCG_MCASE(15) ACCG_MCASE(16)
+        default: return hipErrorInvalidValue;
+      }
+#undef ACCG_MCASE
+      return hipGetLastError();
+    }
+  }
   if (LPP == 16) {
     switch (K) {
       ACCG_CASE(1) ACCG_CASE(2) ACCG_CASE(3) ACCG_CASE(4) ACCG_CASE(5) ACCG_CASE(6) ACCG_CASE(7) ACCG_CASE(8)
@@ -479,8 +534,9 @@ hipError_t sw_trace_launch(int K, int lpp, bool pack16, bool lane_is_alt, const 
                            int cap, hipStream_t s) {
   if (n == 0) return hipSuccess;
   const uint32_t threads = n * 8, block = 64, grid = (threads + block - 1) / block;
-  if (lane_is_alt) hipLaunchKernelGGL((sw_trace_kernel<true>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap);
-  else hipLaunchKernelGGL((sw_trace_kernel<false>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap);
+  const int masks = a.bt_masks && pack16 && lpp == 16 ? 1 : 0;
+  if (lane_is_alt) hipLaunchKernelGGL((sw_trace_kernel<true>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap, masks);
+  else hipLaunchKernelGGL((sw_trace_kernel<false>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap, masks);
   return hipGetLastError();
 }
 

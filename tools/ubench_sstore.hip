@@ -48,6 +48,23 @@ __global__ __launch_bounds__(64) void k(uint32_t* out, uint4* rec, int steps) {
           p0 ^= x;
         }
       }
+      if (MODE == 5 || MODE == 6) {      // what a compare costs by encoding: 8 x VOP3 v_cmp_lt_i16 (low halves only) / 8 x v_cmp_lt_i32, no stores
+        if (MODE == 5)
+          asm volatile(
+              "v_cmp_lt_i16_e64 s[40:41], %0, %1\n\tv_cmp_lt_i16_e64 s[42:43], %1, %2\n\tv_cmp_lt_i16_e64 s[44:45], %2, %3\n\tv_cmp_lt_i16_e64 s[46:47], %3, %0\n\t"
+              "v_cmp_lt_i16_e64 s[48:49], %0, %2\n\tv_cmp_lt_i16_e64 s[50:51], %1, %3\n\tv_cmp_lt_i16_e64 s[52:53], %2, %0\n\tv_cmp_lt_i16_e64 s[54:55], %3, %1\n\t"
+              : : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+              : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");
+        else
+          asm volatile(
+              "v_cmp_lt_i32_e64 s[40:41], %0, %1\n\tv_cmp_lt_i32_e64 s[42:43], %1, %2\n\tv_cmp_lt_i32_e64 s[44:45], %2, %3\n\tv_cmp_lt_i32_e64 s[46:47], %3, %0\n\t"
+              "v_cmp_lt_i32_e64 s[48:49], %0, %2\n\tv_cmp_lt_i32_e64 s[50:51], %1, %3\n\tv_cmp_lt_i32_e64 s[52:53], %2, %0\n\tv_cmp_lt_i32_e64 s[54:55], %3, %1\n\t"
+              : : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+              : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");
+        unsigned x;
+        asm volatile("s_xor_b32 %0, s40, s55" : "=s"(x));
+        p0 ^= x;
+      }
       if (MODE == 3) {
         s2 d0 = __builtin_elementwise_sub_sat(__builtin_bit_cast(s2, a0), __builtin_bit_cast(s2, a1));
         s2 d1 = __builtin_elementwise_sub_sat(__builtin_bit_cast(s2, a1), __builtin_bit_cast(s2, a2));
@@ -85,6 +102,8 @@ int main() {
   if (run<1>("B: A + 80 v_cmp_lt_i16_sdwa -> SGPR masks", out, rec, steps, waves)) return 1;
   if (run<2>("C: B + 40 s_store_dwordx4 (640 B per step)", out, rec, steps, waves)) return 1;
   if (run<3>("D: A + arithmetic extraction (40 x 3 ops) + global_store_dwordx4", out, rec, steps, waves)) return 1;
+  if (run<5>("F: A + 80 v_cmp_lt_i16_e64 (VOP3, low halves) -> SGPR masks", out, rec, steps, waves)) return 1;
+  if (run<6>("G: A + 80 v_cmp_lt_i32_e64 -> SGPR masks", out, rec, steps, waves)) return 1;
   if (run<4>("E: C with s_waitcnt lgkmcnt(0) in front of every row's compares", out, rec, steps, waves)) return 1;
   // what E left in memory against what C left (same inputs, same addresses): a difference = C overwrote SGPRs a store had not read yet
   {
