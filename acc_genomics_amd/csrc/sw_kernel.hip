@@ -21,6 +21,8 @@
 // (EXEC) before their first and after their last sweep position, which freezes exactly the values
 // the end-cell rule needs: the registers end up holding H[.][last sweep position], and the last
 // lane's last position is logged to LDS every step.  No MFMA: integer max-plus recurrence.
+#include <stdlib.h>
+#include <algorithm>
 #include "sw_dev.h"
 
 namespace accg {
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(64) void sw_kernel(SwArgs a, uint32_t work_base, ui
 // Restates calculateCigarOneBatch (FalconSW_AVX.cpp:2341-2417) on top of the bit planes: the walk, the
 // strategy-specific tail, alignment_offset and the final reversal.
 template <bool LANE_IS_ALT>
-__global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap, int masks) {
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void sw_trace_pairs(const SwArgs& a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap, int masks,
+                                               const uint32_t tid) {
   const uint32_t wi = tid >> 3, slot = tid & 7;
   const uint32_t pair = wi < n_work ? a.work[work_base + wi].pair[slot] : SW_NO_PAIR;
   const int g = slot >> 1, half = slot & 1;
@@ -470,6 +472,15 @@ __global__ void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, u
   const int2* src = reinterpret_cast<const int2*>(el);
   for (int x = 0; x < n; x++) dst[x] = src[n - 1 - x];
 }
+// The walk is latency bound (dependent loads) and shares the chip with the NEXT slice's fill, which wants its four wavefronts per SIMD:
+// a grid of every pair at once puts two to three backtrace wavefronts on every SIMD and pushes a fill wavefront off each of them, so the
+// grid is capped (ACCG_SW_TRACE_WAVES wavefronts, sw_host.cpp) and every wavefront walks its share of the slice's pairs, 64 at a time.
+template <bool LANE_IS_ALT>
+__global__ __launch_bounds__(64) void sw_trace_kernel(SwArgs a, uint32_t work_base, uint32_t n_work, uint32_t bt_first, int K, int LPP, int p16, int sweep_cap, int masks) {
+  const uint32_t n_threads = n_work * 8u;
+  for (uint32_t base = blockIdx.x * 64u; base < n_threads; base += gridDim.x * 64u)
+    sw_trace_pairs<LANE_IS_ALT>(a, work_base, n_work, bt_first, K, LPP, p16, sweep_cap, masks, base + threadIdx.x);
+}
 
 template <int LPP, bool P16, bool LIA, bool BT>
 hipError_t launch(int K, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first, int cap, hipStream_t st) {
@@ -533,7 +544,11 @@ hipError_t sw_launch(int K, int lpp, bool pack16, bool lane_is_alt, bool with_bt
 hipError_t sw_trace_launch(int K, int lpp, bool pack16, bool lane_is_alt, const SwArgs& a, uint32_t wb, uint32_t n, uint32_t bt_first,
                            int cap, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  const uint32_t threads = n * 8, block = 64, grid = (threads + block - 1) / block;
+  // (default 1024 = one per SIMD of the 256 CUs: configs[2] with CIGARs 19.0 -> 18.1 ms; 512: 20.2, the walk becomes the longer half;
+  // 768 ... 4096: 18.0-18.5 and 19.0; ACCG_SW_TRACE_WAVES=-1: a wavefront per 64 pairs as before)
+  static const int wave_knob = [] { const char* e = getenv("ACCG_SW_TRACE_WAVES"); return e ? atoi(e) : 0; }();
+  const uint32_t wave_cap = wave_knob < 0 ? 0u : wave_knob > 0 ? (uint32_t)wave_knob : 1024u;
+  const uint32_t threads = n * 8, block = 64, all = (threads + block - 1) / block, grid = wave_cap ? std::min(all, wave_cap) : all;
   const int masks = a.bt_masks && pack16 && lpp == 16 ? 1 : 0;
   if (lane_is_alt) hipLaunchKernelGGL((sw_trace_kernel<true>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap, masks);
   else hipLaunchKernelGGL((sw_trace_kernel<false>), dim3(grid), dim3(block), 0, s, a, wb, n, bt_first, K, lpp, (int)pack16, cap, masks);
