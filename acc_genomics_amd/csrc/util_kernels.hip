@@ -40,17 +40,17 @@ __global__ __launch_bounds__(256) void k_phmm_results(const uint32_t* __restrict
 }
 // the same for a batch whose fp64 values were computed speculatively for every pair (no planner, nothing counted on the way): ONE block
 // counts the pairs below MIN_ACCEPTED (1e-28f, host_type.h:21) while it copies the fp32 results, and sends the fp64 values if there are any
-__global__ __launch_bounds__(1024) void k_phmm_results_spec(const float* __restrict__ raw, const uint32_t* __restrict__ out64, size_t n, uint32_t* __restrict__ stage,
+__global__ __launch_bounds__(256) void k_phmm_results_spec(const float* __restrict__ raw, const uint32_t* __restrict__ out64, size_t n, uint32_t* __restrict__ stage,
                                                             size_t off64_words, const unsigned long long* tick) {
   __shared__ unsigned s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   unsigned mine = 0;
-  for (size_t i = threadIdx.x; i < n; i += 1024) { const float v = raw[i]; stage[4 + i] = __float_as_uint(v); mine += v < 1e-28f; }
+  for (size_t i = threadIdx.x; i < n; i += 256) { const float v = raw[i]; stage[4 + i] = __float_as_uint(v); mine += v < 1e-28f; }
   if (mine) atomicAdd(&s_cnt, mine);
   __syncthreads();
   const unsigned cnt = s_cnt;
-  if (cnt) for (size_t i = threadIdx.x; i < 2 * n; i += 1024) stage[off64_words + i] = out64[i];
+  if (cnt) for (size_t i = threadIdx.x; i < 2 * n; i += 256) stage[off64_words + i] = out64[i];
   if (threadIdx.x == 0) {
     const unsigned long long t = tick ? wall_clock64() - *tick : 0ull;
     stage[0] = (uint32_t)t; stage[1] = (uint32_t)(t >> 32); stage[2] = cnt; stage[3] = 0u;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void k_phmm_results_spec(const float* __restr
 
 namespace accg {
 hipError_t phmm_results_spec_by_kernel(const float* raw, const double* out64, size_t n, void* stage_pinned, size_t off64_bytes, const unsigned long long* tick, hipStream_t s) {
-  hipLaunchKernelGGL(k_phmm_results_spec, dim3(1), dim3(1024), 0, s, raw, (const uint32_t*)out64, n, (uint32_t*)stage_pinned, off64_bytes / 4, tick);
+  hipLaunchKernelGGL(k_phmm_results_spec, dim3(1), dim3(256), 0, s, raw, (const uint32_t*)out64, n, (uint32_t*)stage_pinned, off64_bytes / 4, tick);
   return hipGetLastError();
 }
 hipError_t upload_by_kernel(const void* host_pinned, void* dev, size_t bytes, unsigned long long* tick, hipStream_t s) {

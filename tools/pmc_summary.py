@@ -23,7 +23,8 @@ for f in glob.glob(os.path.join(root, "pmc_%s_*" % tag, "*", "*counter_collectio
         elif "sw_trace_kernel" in name:
             k = "sw_trace"
         elif "sw_kernel" in name:
-            k = "sw_fill_bt" if name.split(">(")[0].rstrip().endswith("true") else "sw"
+            targs = [x.strip() for x in name.split("sw_kernel<", 1)[1].split(">(")[0].split(",")]      # K, lanes, int16, lane_is_alt, record, [lane-mask record]
+            k = "sw_fill_bt" if len(targs) >= 5 and targs[4] == "true" else "sw"
         elif "smem_kernel" in name:
             k = "smem"
         else:
