@@ -76,9 +76,13 @@ struct accg_ctx {
   uint32_t* h_flags = nullptr;
   uint32_t flag_next = 0;
   bool oneshot = false;
+  bool spec_hint = false;       // the last pass whose results were fetched on this context rescued something (phmm_host.cpp: results_finish)
   bool alone = true;            // ... and no other caller is known to share the device right now (a mux tells: false while other lanes are busy)
   int wall_khz = 100000;        // rate of the device's constant wall clock (wall_clock64): 100 MHz on every gfx9
   // uploads and result blocks up to this size travel by copy kernels on the stream instead of hipMemcpyAsync (ACCG_COPY_KERNEL_MAX, bytes; 0 = never)
+  // (2 MiB.  Measured at 512 KiB: a lone configs[1] region call, whose 1.5 MB upload then goes through the DMA engine, 0.53-0.56 against
+  // 0.55-0.68 ms -- but sixteen callers through a mux 54 against 37 us per region: their batches of four regions and more fall back
+  // to DMA copies, which queue behind each other across the lanes)
   size_t kernel_copy_max = 2u << 20;
   // Independent kernels of one pass (one launch per rows-per-lane class) are spread over these streams, forked from and
   // joined back to `stream`: queued on one stream each launch would wait for the previous one's last wavefront.

@@ -1300,7 +1300,10 @@ static int phmm_batch_create_impl(accg_ctx* ctx, int n_regions, const void* cons
   // them, and none that could need the strict re-run launch.  ACCG_PHMM_SPEC=0 turns it off.
   {
     static const bool spec_off_env = [] { const char* e = getenv("ACCG_PHMM_SPEC"); return e && e[0] == '0'; }();
-    bool ok = ctx->oneshot && ctx->alone && !spec_off_env && b->all_form5 && !b->redo_possible && !b->rd.empty();
+    // ... and only when the call before on this context had something to rescue: the fp64 pass over every read is longer than the
+    // sweep, so on data that never underflows fp32 the speculation would cost a region a quarter more (100 reads x 10 haplotypes, all
+    // related: 0.118 ms without, 0.135-0.158 with); a caller's regions come from one data set, the last one is the best predictor there is
+    bool ok = ctx->oneshot && ctx->alone && ctx->spec_hint && !spec_off_env && b->all_form5 && !b->redo_possible && !b->rd.empty();
     uint64_t n_items[PHMM_RESCUE_CLASSES] = {0};
     if (ok) {
       for (size_t ri = 0; ri < b->regions.size() && ok; ri++) {
@@ -1803,6 +1806,7 @@ int results_finish(accg_phmm_batch* b, const ResultDst* dst, size_t n_dst) {
   memcpy(&ticks, stage, sizeof ticks);
   memcpy(&nresc, stage + sizeof ticks, sizeof nresc);
   if (b->kernel_copies && ticks) b->last_kernel_ns = (uint64_t)((double)ticks * 1e6 / (double)b->ctx->wall_khz);
+  b->ctx->spec_hint = nresc != 0;
   const float* raw = (const float*)(stage + RES_HDR);
   const double* r64 = (const double*)(stage + off64);
   bool want_l10 = false;
