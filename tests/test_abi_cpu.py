@@ -108,3 +108,16 @@ def test_hand_counted_lds_waits_hold_in_the_built_code():
         pytest.skip("no build directory (prebuilt library only)")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_phmm_asm.py")] + objs, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_compat_library_exports_the_reference_entry_points():
+    """libaccg_compat.so (the reference's entry-point names on top of the C ABI) loads without a GPU and exports the task plugin's
+    create / destroy, compute_fpga, the FalconPairHMM class with its CPU hook, the process-wide mux accessor and the SW entry points."""
+    so = os.path.join(ROOT, "acc_genomics_amd", "libaccg_compat.so")
+    assert os.path.exists(so)
+    syms = os.popen("nm -D --defined-only %s | c++filt" % so).read()
+    for name in ("create", "destroy", "compute_fpga(", "FalconPairHMM::computePairhmm(", "FalconPairHMM_set_cpu_fallback(", "accg_compat_mux()",
+                 "FalconSWFPGA_run(", "FalconSWFPGA_set_cpu_fallback(", "_smithWatermanRun(", "SWPairwiseAlignmentMultiBatch(", "smem_ocl(", "serialize("):
+        assert name in syms, name
+    drv = os.path.join(ROOT, "tests", "cpp", "libdropin_bench.so")
+    assert os.path.exists(drv) and "dropin_bench" in os.popen("nm -D --defined-only %s" % drv).read()
