@@ -144,6 +144,14 @@ accg_ctx* ctx() {
   }
   return g_ctx;
 }
+// The HIP runtime maps streams onto four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and it reads that variable when it
+// first comes up.  This library is loaded by a process whose accelerator work is the mux's lanes -- six small kernel chains side by
+// side -- so, unless the variable is set already (or ACCG_KEEP_HW_QUEUES=1), it asks for eight at load time: + 6 % at sixteen caller
+// threads (task plugin 1.89 -> 2.01 TCUPS).
+__attribute__((constructor)) void accg_compat_hw_queues() {
+  const char* keep = getenv("ACCG_KEEP_HW_QUEUES");
+  if (!(keep && keep[0] == '1')) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
 // ... and one process-wide mux for the PairHMM entry points (include/accg.h: accg_phmm_mux): compute_fpga, every FalconPairHMM object
 // and every task instance put their region through it, so callers on several threads -- an accelerator manager runs several task
 // instances at a time -- share device batches instead of queueing small kernels behind each other.  ACCG_MUX_LANES (default 6) and
