@@ -815,12 +815,10 @@ void partition(accg_phmm_batch& b) {
   // Two passes over the regions.  The first, serial and cheap, cuts each region's haplotypes into runs and hands out the places of
   // what the second one writes (run table, haplotype lists, streams, jobs); the second fills them region by region, independently,
   // on the host's threads.
-  struct RegPlan { std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens; uint32_t chunk0 = 0, ids0 = 0, job0 = 0, n_jobs = 0, rchunk0 = 0; size_t stream0 = 0; };
+  struct RegPlan { std::vector<std::pair<uint32_t, uint32_t>> runs; std::vector<uint32_t> lens; uint32_t chunk0 = 0, ids0 = 0, job0 = 0, n_jobs = 0; size_t stream0 = 0; };
   std::vector<RegPlan> plan(b.regions.size());
   // (measured and dropped, round 4: rescue items of ONE haplotype each instead of the sweep's runs for batches of up to a few hundred
   // regions -- a 134-region configs[3] shard: planner + rescue 0.481 -> 0.491 ms, 1024 regions 2.52 -> 2.72: no gain at any size)
-  const bool rescue_split = false;
-  uint32_t rchunk_total = 0;
   {
     uint32_t chunk0 = 0, ids0 = 0; size_t stream0 = 0;
     for (size_t ri = 0; ri < b.regions.size(); ri++) {
@@ -833,27 +831,19 @@ void partition(accg_phmm_batch& b) {
         cap_all = std::max(cap_all, (P.lens[c] + 63) / 64 * 64); hmax_all = std::max(hmax_all, P.runs[c].second);
         ids0 += P.runs[c].second;
         stream0 += (P.lens[c] + PHMM_STREAM_TAIL + 15) / 16 * 16;
-        if (!rescue_split) {
-          b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((P.lens[c] + 63) / 64 * 64));
-          b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)P.runs[c].second);
-        }
-      }
-      if (rescue_split) {
-        for (uint32_t k = 0; k < r.n_haps; k++) b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((b.hp[r.hap0 + k].len + 2 + 63) / 64 * 64));
-        b.rescue_haps_cap = std::max(b.rescue_haps_cap, 1);
+        b.rescue_stream_cap = std::max(b.rescue_stream_cap, (int)((P.lens[c] + 63) / 64 * 64));
+        b.rescue_haps_cap = std::max(b.rescue_haps_cap, (int)P.runs[c].second);
       }
       chunk0 += (uint32_t)P.runs.size();
-      const uint32_t n_rchunks = rescue_split ? r.n_haps : (uint32_t)P.runs.size();
-      P.rchunk0 = rchunk_total;
-      rchunk_total += n_rchunks;
-      b.regions_dev[ri] = {r.read0, r.n_reads, P.rchunk0, n_rchunks, r.n_haps, 0};
+      const uint32_t n_rchunks = (uint32_t)P.runs.size();
+      b.regions_dev[ri] = {r.read0, r.n_reads, P.chunk0, n_rchunks, r.n_haps, 0};
       {   // upper bound of rescue jobs per class: a group starts with a distinct read of that class
         uint32_t per_class[PHMM_RESCUE_CLASSES] = {0};
         for (uint32_t k = 0; k < r.n_reads; k++) { int c, l, K; phmm_rescue_class(b.rd[r.read0 + k].len, &c, &l, &K); per_class[c]++; }
         for (int c = 0; c < PHMM_RESCUE_CLASSES; c++) b.rescue_bound[c] += (uint64_t)per_class[c] * (uint64_t)((n_rchunks + 1) / 2 * 2);   // (room for pairs)
       }
     }
-    b.chunks_dev.resize(rchunk_total); b.chunk_stream16.resize(chunk0); b.chunk_stream_len.resize(chunk0);
+    b.chunks_dev.resize(chunk0); b.chunk_stream16.resize(chunk0); b.chunk_stream_len.resize(chunk0);
     b.hap_ids.resize(ids0);
     b.streams.assign(stream0, 0);
   }
@@ -881,9 +871,7 @@ void partition(accg_phmm_batch& b) {
     for (size_t c = 0; c < runs.size(); c++) {
       const auto& run = runs[c];
       ids0[c] = idp;
-      // (the rescue's chunk table: the sweep's runs, or one entry per haplotype -- a region's haplotypes sit in hap_ids in their own order)
-      if (!rescue_split) b.chunks_dev[P.rchunk0 + c] = {idp, run.second};
-      else for (uint32_t k = 0; k < run.second; k++) b.chunks_dev[P.rchunk0 + run.first + k] = {idp + k, 1u};
+      b.chunks_dev[P.chunk0 + c] = {idp, run.second};
       for (uint32_t k = 0; k < run.second; k++) b.hap_ids[idp++] = r.hap0 + run.first + k;
       // the run's stream: [marker][codes] per haplotype, a last marker, zeros (phmm_dev.h)
       b.chunk_stream16[P.chunk0 + c] = (uint32_t)(sp / 16);
