@@ -37,9 +37,16 @@ struct SmemArgs {
   uint32_t* nseg;               //   ... segments per thread
   uint32_t waves_per_cu;        // 0 = whatever fits; else an LDS request that admits this many wavefronts per CU
   uint32_t* queue;              // engine variant: next read of the launch (zeroed before it)
+  uint32_t skip_pass3;          // fused kernel: leave the LAST-like third pass to smem_launch_pass3 on another stream (smem_host.cpp)
 };
 
 hipError_t smem_launch(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s);
+// the third pass by itself (flat: one bwt_extend per iteration, 63 of 64 lanes busy), appending at a.mem_num[read] into a.out; and the
+// kernel that appends such a separate list behind the first two passes' intervals (out, their counts num12; the final count goes to num),
+// capped like every push
+hipError_t smem_launch_pass3(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s);
+hipError_t smem_launch_merge3(SmemIntv* out, int32_t* num, const int32_t* num12, uint32_t max_out, const SmemIntv* out3, const int32_t* num3, uint32_t max3,
+                              uint32_t read_base, uint32_t n_reads, hipStream_t s);
 // fills ktab (SMEM_KTAB_ENTRIES x uint4) level by level with the kernel's own bwt_extend; a.ktab is ignored
 hipError_t smem_build_ktab(const SmemArgs& a, uint4* ktab, hipStream_t s);
 // persistent wavefronts that take reads from a queue; compact (32-bit) index only; scratch for n_waves x 64 threads

@@ -28,9 +28,10 @@ struct accg_smem_batch {
   uint32_t *d_seg = nullptr, *d_nseg = nullptr;   // three-kernel path: segment table of the first pass
   uint32_t engine_waves = 0;      // > 0: persistent-wavefront engine (smem_kernel.hip), compact index only
   int32_t* d_num = nullptr;
+  SmemIntv* d_out3 = nullptr; int32_t *d_num3 = nullptr, *d_num12 = nullptr;     // third pass on a stream of its own (ACCG_SMEM_PASS3_ASIDE): its intervals, SMEM_PASS3_SLOTS per read
   uint64_t bases = 0;
   uint32_t longest = 0;         // longest read of the batch (sizes the kernels' LDS rows)
-  ~accg_smem_batch() { for (void* p : {(void*)d_seq, (void*)d_len, (void*)d_out, (void*)d_num, (void*)d_scratch, (void*)d_queue, (void*)d_seg, (void*)d_nseg}) if (p) hipFree(p); }
+  ~accg_smem_batch() { for (void* p : {(void*)d_seq, (void*)d_len, (void*)d_out, (void*)d_num, (void*)d_scratch, (void*)d_queue, (void*)d_seg, (void*)d_nseg, (void*)d_out3, (void*)d_num3, (void*)d_num12}) if (p) hipFree(p); }
 };
 
 extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64_t bwt_words, const uint64_t* bwt_para,
@@ -52,8 +53,8 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
   for (int c = 0; c < 5; c++) x->L2[c] = bwt_para[1 + c];
   // BWA's block (64 B per 128 symbols: 4 x u64 cumulative counts + 8 x 16 symbols) costs a lookup four 16-byte loads and
   // eight words of popcounts.  While the counts fit 32 bits the index is re-laid-out on upload into half-blocks of the
-  // same total size, 32 B per 64 symbols = 4 x u32 counts + the symbols' low and high bits as two 64-bit planes: one sector, two
-  // loads, three masked popcounts per lookup.
+  // same total size, 32 B per 64 symbols = 4 x u32 counts (cumulated from base 3 down) + the symbols' low and high bits as two
+  // 64-bit planes: one sector, two loads, two masked popcounts per lookup.
   // The counts a lookup returns are the same numbers.  ACCG_SMEM_COMPACT=0 keeps the caller's layout.
   const uint64_t n_blocks = bwt_words / 16;
   const char* ec = getenv("ACCG_SMEM_COMPACT");
@@ -61,6 +62,9 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
   ACCG_HIP(hipMalloc((void**)&x->d_bwt, bwt_words * 4));
   if (x->compact) {
     std::vector<uint32_t> cb(bwt_words);
+    uint32_t T[4];
+    T[3] = (uint32_t)x->L2[3] + 1u;
+    for (int j = 2; j >= 0; j--) T[j] = T[j + 1] + (uint32_t)x->L2[j] + 1u;
 #pragma omp parallel for schedule(static) num_threads(accg::host_threads())
     for (int64_t b = 0; b < (int64_t)n_blocks; b++) {
       const uint32_t* src = bwt + b * 16;
@@ -70,7 +74,8 @@ extern "C" int accg_smem_index_create(accg_ctx* ctx, const uint32_t* bwt, uint64
       for (int s = 0; s < 4; s++) c[s] = src[2 * s];              // low words of the u64 counts (high words are 0 here)
       for (int half = 0; half < 2; half++) {
         uint32_t* d = half ? d1 : d0;
-        for (int s = 0; s < 4; s++) d[s] = c[s];
+        // cumulated from the top: symbols >= j in front of the half-block, plus T[j] = sum over b >= j of (L2[b] + 1) (smem_kernel.hip, count_ge)
+        d[3] = c[3] + T[3]; d[2] = c[2] + c[3] + T[2]; d[1] = c[1] + c[2] + c[3] + T[1]; d[0] = c[0] + c[1] + c[2] + c[3] + T[0];
         uint64_t lo = 0, hi = 0;                                   // bit planes: symbol p of the half-block at bit p
         for (int j = 0; j < 4; j++) {
           const uint32_t v = src[8 + 4 * half + j];                // 16 symbols, first in the top bits
@@ -177,6 +182,32 @@ extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
     return ACCG_OK;
   }
   a.queue = nullptr;
+  a.skip_pass3 = 0;
+  // The third pass (LAST-like forward seeds: 28 % of the lookups, flat, memory bound with all lanes busy) beside the fused kernel's first
+  // two (latency bound at a fifth of the lanes) instead of behind them in the same threads: it only appends, so it runs on a forked
+  // stream into a list of its own and a small kernel appends that list afterwards.  ACCG_SMEM_PASS3_ASIDE=0/1.
+  static const int aside_knob = [] { const char* e = getenv("ACCG_SMEM_PASS3_ASIDE"); return e ? atoi(e) : 1; }();
+  if (aside_knob >= 1 && !counting && !b->d_seg && b->n) {
+    constexpr uint32_t SLOTS = 16;            // a reported seed is at least 20 bases: at most 12 per read of 255
+    accg_ctx* c = x->ctx;
+    const size_t n1 = b->n;
+    if (!b->d_out3) { ACCG_HIP(hipMalloc((void**)&b->d_out3, n1 * SLOTS * sizeof(SmemIntv))); ACCG_HIP(hipMalloc((void**)&b->d_num3, n1 * sizeof(int32_t))); ACCG_HIP(hipMalloc((void**)&b->d_num12, n1 * sizeof(int32_t))); }
+    ACCG_HIP(ctx_fork(c));                                  // (behind the previous run's merge, which reads the list)
+    hipStream_t side = c->aux[0];
+    ACCG_HIP(hipMemsetAsync(b->d_num3, 0, n1 * sizeof(int32_t), side));
+    SmemArgs a3 = a;
+    a3.out = b->d_out3; a3.mem_num = b->d_num3; a3.max_out = SLOTS; a3.seg = nullptr;
+    a.skip_pass3 = 1; a.mem_num = b->d_num12;
+    for (uint32_t r0 = 0; r0 < b->n; r0 += b->slice) {
+      const uint32_t m = std::min(b->slice, b->n - r0);
+      ACCG_HIP(smem_launch(a, r0, m, c->stream));
+      ACCG_HIP(smem_launch_pass3(a3, r0, m, side));
+    }
+    ACCG_HIP(ctx_join(c));
+    for (uint32_t r0 = 0; r0 < b->n; r0 += b->slice)
+      ACCG_HIP(smem_launch_merge3(b->d_out, b->d_num, b->d_num12, b->max_out, b->d_out3, b->d_num3, SLOTS, r0, std::min(b->slice, b->n - r0), c->stream));
+    return ACCG_OK;
+  }
   for (uint32_t r0 = 0; r0 < b->n; r0 += b->slice)
     ACCG_HIP(counting ? smem_launch_count(a, r0, std::min(b->slice, b->n - r0), x->ctx->stream) : smem_launch(a, r0, std::min(b->slice, b->n - r0), x->ctx->stream));
   return ACCG_OK;

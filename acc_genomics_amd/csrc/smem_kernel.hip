@@ -53,6 +53,12 @@ __device__ __forceinline__ void smem_count(int which, unsigned n) {      // n is
 #define ACCG_SMEM_COUNT(which, n) ((void)0)
 #endif
 
+#ifndef SMEM_KEEP_LAST_BACK
+#define SMEM_KEEP_LAST_BACK 0
+#endif
+#ifndef SMEM_SHARE_KL
+#define SMEM_SHARE_KL 1      // 1: k and l in one half-block share the fetch (lanes that need a second one fetch it under EXEC); 0: always two fetches
+#endif
 constexpr int MIN_SEED_LEN = 19;   // smem/common/common.h:37
 
 // bwtintv_t with `info` kept as its two halves: lo = end of the match (query position), hi = its start (or, inside
@@ -112,35 +118,50 @@ __device__ __forceinline__ void occ4_2(const Ctx<uint64_t>& f, uint64_t k, uint6
   occ4(f, k, tk); occ4(f, l, tl);
 }
 // ... over the half-block layout: 32 B per 64 symbols = 4 x u32 counts + the 64 symbols as two bit planes (low bits, high bits;
-// symbol p of the half-block at bit p).  A count up to position r is then three masked 64-bit popcounts -- a quarter of the
-// integer work of the 2-bit words above, and this kernel's backward halves are bound by instruction issue.
+// symbol p of the half-block at bit p).  An extension by base c needs, at k and at l, two numbers only: how many symbols up to there
+// are >= c and how many are > c (Occ of c is their difference; the sizes of the bases above c, which stack up the other strand's
+// bound, sum to the difference of the second between l and k).  So the header holds the counts cumulated from the top --
+// H[j] = symbols >= j in front of the half-block, H[0] = its first position -- and a lane fetches the pair (H[c], H[c+1]) by address
+// (H[4] = 0 is not stored: selected).  The host adds T[j] = sum over b >= j of (L2[b] + 1) to H[j] (smem_host.cpp), so that the
+// difference of the pair at k is L2[c] + 1 + Occ(c, k) -- the new bound of the strand looked up -- as it stands, while T cancels in
+// everything that is a difference between l and k (all arithmetic mod 2^32).
+// Both sets are one three-input boolean of the planes and two all-or-nothing words made from c's bits:
+//   >= c :  c = 0 all, 1 lo|hi, 2 hi, 3 lo&hi   =  c1 ? hi & (lo | ~c0) : hi | (lo | ~c0)
+//   >  c :  c = 0 lo|hi, 1 hi, 2 lo&hi, 3 none  =  c1 ? hi & (lo & ~c0) : hi | (lo & ~c0)
+// -- two masked 64-bit popcounts per lookup and no selection among four counts afterwards (round 4: ~105 -> ~65 VALU instructions
+// per extension; this kernel's backward halves are bound by instruction issue).
 // When k and l fall into one half-block (the usual case once the interval is narrower than a block) it is fetched once; lanes
 // that do need a second one fetch it under EXEC.
-__device__ __forceinline__ void count_planes(const uint4 h, const uint4 pl, uint32_t r, uint32_t cnt[4]) {
+struct __attribute__((packed, aligned(4))) HdrPair { uint32_t x, y; };      // (H[c], H[c+1]): 4-byte aligned
+struct BaseSel { uint32_t c0m, c1m; bool c3; uint32_t hoff; };     // per extension: all-ones words from c's two bits, c == 3, 4 * c
+__device__ __forceinline__ BaseSel base_sel(int c) {
+  BaseSel b; b.c0m = (uint32_t)-(c & 1); b.c1m = (uint32_t)-((c >> 1) & 1); b.c3 = c == 3; b.hoff = (uint32_t)c << 2;
+  return b;
+}
+__device__ __forceinline__ uint32_t bcnt_add(uint32_t x, uint32_t acc) {      // popcount(x) + acc in one instruction (the compiler prefers v_bcnt + v_add3)
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+// a = symbols >= c, b = symbols > c among the first r + 1 of the half-block, on top of the header pair hd.  Per 32 bits of the planes
+// five v_bitop3/v_and (truth tables over a = 0xF0, b = 0xCC, c = 0xAA) and two v_bcnt that add as they count.
+__device__ __forceinline__ void count_ge(const HdrPair hd, const uint4 pl, uint32_t r, const BaseSel& bs, uint32_t& a, uint32_t& b) {
   const uint64_t m = ~0ull >> (63u - r);
-  const uint64_t lo = (((uint64_t)pl.y << 32) | pl.x) & m, hi = (((uint64_t)pl.w << 32) | pl.z) & m;
-  const uint32_t c1 = (uint32_t)__popcll(lo & ~hi), c2 = (uint32_t)__popcll(hi & ~lo), c3 = (uint32_t)__popcll(hi & lo);
-  cnt[1] = h.y + c1; cnt[2] = h.z + c2; cnt[3] = h.w + c3; cnt[0] = h.x + (r + 1u) - c1 - c2 - c3;
+  const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+  const uint32_t h0 = pl.z & m0, h1 = pl.w & m1;
+  const uint32_t ge0 = __builtin_amdgcn_bitop3_b32(pl.x, bs.c0m, m0, 0xA2), ge1 = __builtin_amdgcn_bitop3_b32(pl.y, bs.c0m, m1, 0xA2);   // (lo | ~c0) & m
+  const uint32_t gt0 = __builtin_amdgcn_bitop3_b32(pl.x, bs.c0m, m0, 0x20), gt1 = __builtin_amdgcn_bitop3_b32(pl.y, bs.c0m, m1, 0x20);   // (lo & ~c0) & m
+  const uint32_t a0 = __builtin_amdgcn_bitop3_b32(h0, ge0, bs.c1m, 0xD4), a1 = __builtin_amdgcn_bitop3_b32(h1, ge1, bs.c1m, 0xD4);        // c1 ? h & p : h | p
+  const uint32_t b0 = __builtin_amdgcn_bitop3_b32(h0, gt0, bs.c1m, 0xD4), b1 = __builtin_amdgcn_bitop3_b32(h1, gt1, bs.c1m, 0xD4);
+  a = bcnt_add(a1, bcnt_add(a0, hd.x));
+  b = bcnt_add(b1, bcnt_add(b0, bs.c3 ? 0u : hd.y));
 }
 // bwt_occ4's k == -1 case (:19) cannot occur here and is not tested for: every interval bound this kernel holds is >= 1
 // (set_intv1 starts at L2[c] + 1, bwt_extend yields L2[b] + 1 + count and other-strand bound + non-negative terms), so k = bound - 1 >= 0.
-__device__ __forceinline__ void occ4_2(const Ctx<uint32_t>& f, uint32_t k, uint32_t l, uint32_t tk[4], uint32_t tl[4]) {
-  k -= (k >= f.primary); l -= (l >= f.primary);
-  const uint4* bk = reinterpret_cast<const uint4*>(f.bwt + ((k >> 6) << 3));
-  uint4 h = bk[0], pl = bk[1];
-  count_planes(h, pl, k & 63u, tk);
-  ACCG_SMEM_COUNT(0, (k >> 6) != (l >> 6) ? 2u : 1u);
-  ACCG_SMEM_COUNT(2, 1u);
-  if ((k >> 6) != (l >> 6)) {
-    const uint4* bl = reinterpret_cast<const uint4*>(f.bwt + ((l >> 6) << 3));
-    h = bl[0]; pl = bl[1];
-  }
-  count_planes(h, pl, l & 63u, tl);
-}
 
 // bwt_extend (baseline.cpp:87-100), returning only the interval of base c; x[is_back ? 0 : 1] is the strand that is looked up
-template <typename IT>
-__device__ __forceinline__ Intv<IT> extend(const Ctx<IT>& f, const Intv<IT>& ik, bool is_back, int c) {
+__device__ __forceinline__ Intv<uint64_t> extend(const Ctx<uint64_t>& f, const Intv<uint64_t>& ik, bool is_back, int c) {
+  typedef uint64_t IT;
   IT tk[4], tl[4];
   const IT look = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
   occ4_2(f, (IT)(look - 1), (IT)(look - 1 + ik.x2), tk, tl);
@@ -161,21 +182,70 @@ __device__ __forceinline__ Intv<IT> extend(const Ctx<IT>& f, const Intv<IT>& ik,
   r.set(0, 0);
   return r;
 }
+// ... over the half-blocks (bwt_2occ4 :40-85 and bwt_extend in one: see count_ge)
+__device__ __forceinline__ Intv<uint32_t> extend(const Ctx<uint32_t>& f, const Intv<uint32_t>& ik, bool is_back, int c) {
+  const uint32_t look = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
+  const uint32_t k0 = look - 1, l0 = look - 1 + ik.x2;
+  const uint32_t pk = k0 >= f.primary, pl_ = l0 >= f.primary;       // the sentinel is not stored: positions behind it move up by one
+  const uint32_t k = k0 - pk, l = l0 - pl_;
+  const BaseSel bs = base_sel(c);
+  const char* base = reinterpret_cast<const char*>(f.bwt);
+  const uint32_t ok = (k >> 6) << 5, ol = (l >> 6) << 5;
+  HdrPair hd = *reinterpret_cast<const HdrPair*>(base + (ok + bs.hoff));
+  uint4 pl = *reinterpret_cast<const uint4*>(base + ok + 16);
+  uint32_t ak, bk, al, bl;
+  count_ge(hd, pl, k & 63u, bs, ak, bk);
+  ACCG_SMEM_COUNT(0, ok != ol ? 2u : 1u);
+  ACCG_SMEM_COUNT(2, 1u);
+#if SMEM_SHARE_KL
+  if (ok != ol)
+#endif
+  {
+    hd = *reinterpret_cast<const HdrPair*>(base + (ol + bs.hoff));
+    pl = *reinterpret_cast<const uint4*>(base + ol + 16);
+  }
+  count_ge(hd, pl, l & 63u, bs, al, bl);
+  const uint32_t lk = ak - bk;                                      // L2[c] + 1 + Occ(c, k): the header carries L2[c] + 1
+  const uint32_t o = other + (pl_ - pk) + (bl - bk);                // the sizes of the bases above c; pl_ - pk = 1 exactly when the sentinel lies inside (k0, l0]: look <= primary <= look + x2 - 1
+  Intv<uint32_t> r;
+  r.x0 = is_back ? lk : o;
+  r.x1 = is_back ? o : lk;
+  r.x2 = (al - bl) - lk;
+  r.info = 0;
+  return r;
+}
 
 template <typename IT>
 __device__ __forceinline__ Intv<IT> set_intv1(const Ctx<IT>& f, int c) {      // baseline.h:6
   Intv<IT> ik;
-  ik.x0 = f.L2[c] + 1; ik.x2 = f.L2[c + 1] - f.L2[c]; ik.x1 = f.L2[3 - c] + 1; ik.set(0, 0);
+  // (selected, not indexed: an array indexed by a lane's value lives in scratch memory, one more round trip in front of every call)
+  const IT l0 = f.L2[0], l1 = f.L2[1], l2 = f.L2[2], l3 = f.L2[3], l4 = f.L2[4];
+  const bool c0 = c == 0, c1 = c == 1, c2 = c == 2;
+  const IT lo = c0 ? l0 : c1 ? l1 : c2 ? l2 : l3;
+  const IT up = c0 ? l1 : c1 ? l2 : c2 ? l3 : l4;
+  const IT rc = c0 ? l3 : c1 ? l2 : c2 ? l1 : l0;
+  ik.x0 = lo + 1; ik.x2 = up - lo; ik.x1 = rc + 1; ik.set(0, 0);
   return ik;
 }
 
 template <typename IT>
-struct Lists {            // thread-interleaved scratch: SMEM_CURR_CAP curr entries, then 256 back entries
+struct Lists {            // thread-interleaved scratch (lists_of): SMEM_CURR_CAP curr entries, then 256 back entries
   Intv<IT>* base; uint32_t stride;
   int curr0;              // first curr entry of the bwt_smem1a_new call in progress (the split path keeps every call's list)
   __device__ __forceinline__ Intv<IT>& curr(int e) const { return base[(size_t)(curr0 + e) * stride]; }
   __device__ __forceinline__ Intv<IT>& back(int e) const { return base[(size_t)(SMEM_CURR_CAP + e) * stride]; }
 };
+
+// Entry e of thread t of the launch at [e * n_threads + t]: a wave instruction touches one run of 1 KB.  (Round 4 measured two other
+// layouts on configs[4]: a block of SMEM_SCRATCH_ENTRIES x 64 per wavefront -- every entry a wavefront touches in one or two 2 MB
+// pages -- 10.39 against 10.05 ms, and one run of SMEM_SCRATCH_ENTRIES records per lane -- consecutive entries share a 64-byte
+// fetch -- 10.73 ms.)
+template <typename IT>
+__device__ __forceinline__ Lists<IT> lists_of(const SmemArgs& a, uint32_t tid) {
+  Lists<IT> L;
+  L.base = reinterpret_cast<Intv<IT>*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  return L;
+}
 
 struct Out {
   SmemIntv* a; uint32_t cap; int n;
@@ -194,15 +264,28 @@ struct ReadLds {
   const uint32_t* w;
   __device__ __forceinline__ int operator[](int i) const { return (int)((w[i >> 3] >> ((i & 7) << 2)) & 0xFu); }
 };
-__device__ __forceinline__ ReadLds stage_read(uint32_t* s_read, uint32_t row_words, const uint8_t* src, int len) {
+__device__ __forceinline__ ReadLds stage_read(uint32_t* s_read, uint32_t row_words, const uint8_t* src, int len, uint32_t row_bytes) {
   uint32_t* my = s_read + threadIdx.x * row_words;
+  // eight bases per word of the row.  From a 4-byte-aligned row they arrive as two word loads (while the row has eight bytes left);
+  // byte by byte each load waits for the one before (the guard on len makes them conditional): 150 round trips per read
+  const bool words = (reinterpret_cast<uintptr_t>(src) & 3u) == 0;
   for (int w8 = 0; w8 * 8 < len; w8++) {
     uint32_t packed = 0;
+    if (words && (uint32_t)(w8 * 8 + 8) <= row_bytes) {
+      const uint32_t v0 = *reinterpret_cast<const uint32_t*>(src + w8 * 8), v1 = *reinterpret_cast<const uint32_t*>(src + w8 * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const int pos = w8 * 8 + e;
-      const uint32_t c = pos < len ? src[pos] : 4u;
-      packed |= (c > 4u ? 4u : c) << (e << 2);
+      for (int e = 0; e < 8; e++) {
+        uint32_t c = ((e < 4 ? v0 : v1) >> ((e & 3) << 3)) & 0xFFu;
+        c = w8 * 8 + e < len ? c : 4u;
+        packed |= (c > 4u ? 4u : c) << (e << 2);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int pos = w8 * 8 + e;
+        const uint32_t c = pos < len ? src[pos] : 4u;
+        packed |= (c > 4u ? 4u : c) << (e << 2);
+      }
     }
     my[w8] = packed;
   }
@@ -341,7 +424,11 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
       ik = ci;
       ik.set(ci.lo(), ci.hi() | (uint32_t)x);
       n_back = 0;
-      L.back(n_back++) = ik;
+      // nothing reads the back list behind the call's last entry (the next call starts an empty one): its chain -- the longest, the
+      // match is unique by then and runs back to the previous mismatch -- only counts its steps
+      const bool keep = SMEM_KEEP_LAST_BACK || i != n_curr - 1;
+      if (keep) L.back(n_back) = ik;
+      n_back++;
       int k = x - 1;
       bool stopped = false;
       // The interval of q[k .. end) is the prefix table's entry for that string whichever side it grew from, so while the match
@@ -375,7 +462,8 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
           const uint4 t = f.ktab[smem_ktab_off(ell + j) + code];
           ik.x0 = (IT)t.x; ik.x1 = (IT)t.y; ik.x2 = (IT)t.z;
           ik.set(ci.lo(), ci.hi() | (uint32_t)(x - j));
-          L.back(n_back++) = ik;
+          if (keep) L.back(n_back) = ik;
+          n_back++;
         }
         k = x - n_ok - 1;
       }
@@ -386,7 +474,8 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
         if (nx.x2 < (IT)min_intv) break;
         ik = nx;
         ik.set(ci.lo(), ci.hi() | (uint32_t)k);
-        L.back(n_back++) = ik;
+        if (keep) L.back(n_back) = ik;
+        n_back++;
       }
       b_start = end;
       k_found = n_back - 1;
@@ -438,22 +527,14 @@ __device__ int seed_strategy1(const Ctx<IT>& f, int len, const Q& q, int x, int 
 }
 
 #ifndef SMEM_WAVES_PER_EU
-#define SMEM_WAVES_PER_EU 5     // what the allocator reaches on its own (86 VGPRs); capped to 80 for a sixth wavefront it spills and measures the same
+#define SMEM_WAVES_PER_EU 5     // what the allocator reaches on its own (91 VGPRs); 6 (80 VGPRs, 16 bytes spilled) and 8 (64, 80 bytes) measure the same or worse
 #endif
+// One read through mem_collect_intv_new (baseline.cpp:387-422): the lane's lists L, its LDS row for the read.
 template <typename IT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_PER_EU))) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= n_reads) return;
-  const uint32_t rd = read_base + tid;
-  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
-#pragma unroll
-  for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
+__device__ __forceinline__ void smem_one_read(const SmemArgs& a, const Ctx<IT>& f, uint32_t rd, const Lists<IT>& L, uint32_t* s_read) {
   const int len = a.seq_len[rd];
-  extern __shared__ uint32_t s_read[];
-  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
-  Lists<IT> L; L.base = reinterpret_cast<Intv<IT>*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len, a.seq_stride);
   Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = 0;
-  // mem_collect_intv_new (baseline.cpp:387-422)
   for (int x = 0; x < len;) x = q[x] < 4 ? smem1a_new(f, len, q, x, 1, mem, L) : x + 1;
   const int old_n = mem.n < (int)mem.cap ? mem.n : (int)mem.cap;   // entries beyond the slot are counted, not kept
   for (int k = 0; k < old_n; k++) {
@@ -462,11 +543,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_P
     if (end - start < 28 || p.x2 > 10) continue;
     smem1a_new(f, len, q, (start + end) >> 1, (int)p.x2 + 1, mem, L);
   }
+  if (!a.skip_pass3)
   for (int x = 0; x < len;) {
     if (q[x] < 4) { Intv<IT> m; x = seed_strategy1(f, len, q, x, MIN_SEED_LEN, 20, m); if (m.x2 > 0) mem.push(m); }
     else x++;
   }
   a.mem_num[rd] = mem.n;
+}
+template <typename IT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_PER_EU))) void smem_kernel(SmemArgs a, uint32_t read_base, uint32_t n_reads) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_reads) return;
+  Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
+#pragma unroll
+  for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
+  extern __shared__ uint32_t s_read[];
+  smem_one_read<IT>(a, f, read_base + tid, lists_of<IT>(a, tid), s_read);
 }
 
 
@@ -499,8 +591,8 @@ __global__ __launch_bounds__(64) void smem_fwd_kernel(SmemArgs a, uint32_t read_
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
   extern __shared__ uint32_t s_read[];
-  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
-  Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len, a.seq_stride);
+  Lists<IT> L = lists_of<IT>(a, tid);
   uint32_t* seg = a.seg + tid;
   // one loop, one bwt_extend per iteration: a lane is either inside a forward extension (i < len, q[i] < 4) or between two
   int n_tot = 0, n_seg = 0, x = 0, i = 0, seg0 = 0;
@@ -545,8 +637,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMEM_WAVES_P
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
   extern __shared__ uint32_t s_read[];
-  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
-  Lists<IT> L; L.base = reinterpret_cast<Intv<IT>*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len, a.seq_stride);
+  Lists<IT> L = lists_of<IT>(a, tid);
   Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = 0;
   const int n_seg = (int)a.nseg[tid];
   for (int sgi = 0; sgi < n_seg; sgi++) {                 // first pass: the backward half of every call, on the list the forward kernel left
@@ -576,7 +668,7 @@ __global__ __launch_bounds__(64) void smem_pass3_kernel(SmemArgs a, uint32_t rea
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
   const int len = a.seq_len[rd];
   extern __shared__ uint32_t s_read[];
-  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len);
+  const ReadLds q = stage_read(s_read, a.read_words, a.seq + (size_t)rd * a.seq_stride, len, a.seq_stride);
   Out mem; mem.a = a.out + (size_t)rd * a.max_out; mem.cap = a.max_out; mem.n = a.mem_num[rd];
   // bwt_seed_strategy1 (:306-327) from every restart point (:411-419), one bwt_extend per iteration
   int x = 0, i = 0;
@@ -630,7 +722,7 @@ __global__ __launch_bounds__(64) void smem_engine(SmemArgs a, uint32_t read_base
   Ctx<IT> f; f.bwt = a.bwt; f.primary = (IT)a.primary; f.ktab = sizeof(IT) == 4 ? a.ktab : nullptr;
 #pragma unroll
   for (int c = 0; c < 5; c++) f.L2[c] = (IT)a.L2[c];
-  Lists<IT> L; L.base = reinterpret_cast<I*>(a.scratch) + tid; L.stride = a.n_threads; L.curr0 = 0;
+  Lists<IT> L = lists_of<IT>(a, tid);
   // the lane's current read, 4 bits per base, in LDS (row of 128 B per lane, rows 132 B apart to spread the banks): the
   // state machine looks at a base of the read in almost every transition
   __shared__ uint32_t s_read[64 * 33];
@@ -836,6 +928,41 @@ hipError_t ACCG_SMEM_SUFFIX(smem_launch_engine)(const SmemArgs& a, uint32_t read
   hipLaunchKernelGGL(smem_engine, dim3(n_waves), dim3(64), 0, s, a, read_base, n_reads);
   return hipGetLastError();
 }
+
+#ifndef SMEM_COUNT
+namespace {
+__global__ __launch_bounds__(256) void smem_merge3_kernel(SmemIntv* out, int32_t* num, const int32_t* num12, uint32_t max_out, const SmemIntv* out3, const int32_t* num3,
+                                                          uint32_t max3, uint32_t read_base, uint32_t n_reads) {
+  // four lanes per read (a read has one or two third-pass seeds, at most twelve): lane j moves entries j, j + 4, ...
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x, j0 = t & 3u;
+  if ((t >> 2) >= n_reads) return;
+  const uint32_t rd = read_base + (t >> 2);
+  const int n = num12[rd], n3 = num3[rd];
+  const int kept3 = n3 < (int)max3 ? n3 : (int)max3;
+  const uint4* src = reinterpret_cast<const uint4*>(out3 + (size_t)rd * max3);
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)rd * max_out + n);
+  for (int k = (int)j0; k < kept3; k += 4)
+    if ((uint32_t)(n + k) < max_out) { const uint4 lo = src[2 * k], hi = src[2 * k + 1]; dst[2 * k] = lo; dst[2 * k + 1] = hi; }
+  if (j0 == 0) num[rd] = n + n3;
+}
+}  // namespace
+hipError_t smem_launch_pass3(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
+  if (n_reads == 0) return hipSuccess;
+  const dim3 grid((n_reads + 63) / 64), block(64);
+  const size_t row = (size_t)64 * a.read_words * sizeof(uint32_t);
+  static const int p3_wpc = [] { const char* e = getenv("ACCG_SMEM_PASS3_WPC"); return e && atoi(e) > 0 ? atoi(e) : 12; }();
+  const size_t lds = std::max<size_t>(row, std::min<size_t>(64 * 1024, (160 * 1024 / p3_wpc) & ~(size_t)255));      // twelve wavefronts per CU: where the flat passes sit on the sector ceiling
+  if (a.compact) hipLaunchKernelGGL(smem_pass3_kernel<uint32_t>, grid, block, lds, s, a, read_base, n_reads);
+  else hipLaunchKernelGGL(smem_pass3_kernel<uint64_t>, grid, block, lds, s, a, read_base, n_reads);
+  return hipGetLastError();
+}
+hipError_t smem_launch_merge3(SmemIntv* out, int32_t* num, const int32_t* num12, uint32_t max_out, const SmemIntv* out3, const int32_t* num3, uint32_t max3,
+                              uint32_t read_base, uint32_t n_reads, hipStream_t s) {
+  if (n_reads == 0) return hipSuccess;
+  hipLaunchKernelGGL(smem_merge3_kernel, dim3((uint32_t)(((uint64_t)n_reads * 4 + 255) / 256)), dim3(256), 0, s, out, num, num12, max_out, out3, num3, max3, read_base, n_reads);
+  return hipGetLastError();
+}
+#endif
 
 hipError_t ACCG_SMEM_SUFFIX(smem_launch)(const SmemArgs& a, uint32_t read_base, uint32_t n_reads, hipStream_t s) {
   if (n_reads == 0) return hipSuccess;

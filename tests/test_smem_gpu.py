@@ -123,6 +123,30 @@ def test_ragged_index_size(ctx):
     assert np.array_equal(gnum, wnum) and all(np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]) for k in range(len(reads)))
 
 
+@pytest.mark.parametrize("stride", [150, 151, 153, 200])
+@pytest.mark.parametrize("aside", ["1", "0"])
+def test_row_strides_and_third_pass_placement(ctx, stride, aside, monkeypatch):
+    """Rows of the read matrix at every alignment (aligned rows are staged by word loads, the others byte by byte; a row's last
+    bytes always byte by byte), with the third pass beside the fused kernel (default) and inside it."""
+    monkeypatch.setenv("ACCG_SMEM_PASS3_ASIDE", aside)
+    rng = np.random.default_rng(400 + stride)
+    g = rng.integers(0, 4, size=50000).astype(np.uint8)
+    bwt, para, _ = fmindex.build(g)
+    reads = _reads(rng, g, 300, (1, min(stride, 255))) + _reads(rng, g, 200, (min(stride, 150), min(stride, 150)), sub=0.01, amb=0.0)
+    seq = np.full((len(reads), stride), 4, np.uint8)
+    ln = np.zeros(len(reads), np.uint8)
+    for i, r in enumerate(reads):
+        seq[i, :len(r)] = r
+        ln[i] = len(r)
+    want, wnum = _oracle(bwt, para, seq, ln, 64)
+    with A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, 64) as b:
+        b.run()
+        got, gnum = b.results()
+    assert np.array_equal(gnum, wnum)
+    for k in range(len(reads)):
+        assert np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]), k
+
+
 def test_small_output_slot_counts_but_does_not_store(ctx):
     rng = np.random.default_rng(21)
     g = rng.integers(0, 4, size=20000).astype(np.uint8)

@@ -26,7 +26,11 @@ for f in glob.glob(os.path.join(root, "pmc_%s_*" % tag, "*", "*counter_collectio
             targs = [x.strip() for x in name.split("sw_kernel<", 1)[1].split(">(")[0].split(",")]      # K, lanes, int16, lane_is_alt, record, [lane-mask record]
             k = "sw_fill_bt" if len(targs) >= 5 and targs[4] == "true" else "sw"
         elif "smem_kernel" in name:
-            k = "smem"
+            k = "smem"                      # the fused kernel: first pass + re-seeding (and the third pass when ACCG_SMEM_PASS3_ASIDE=0)
+        elif "smem_pass3_kernel" in name:
+            k = "smem_pass3"                # the third pass beside it on a second stream (round 4)
+        elif "smem_merge3_kernel" in name:
+            k = "smem_merge3"
         else:
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
