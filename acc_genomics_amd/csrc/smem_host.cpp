@@ -170,9 +170,9 @@ extern "C" int accg_smem_batch_run(accg_smem_batch* b) {
   a.out = b->d_out; a.mem_num = b->d_num; a.max_out = b->max_out; a.scratch = b->d_scratch; a.n_threads = b->slice;
   a.seg = b->d_seg; a.nseg = b->d_nseg;
   a.read_words = ((b->longest + 7) / 8) | 1u;
-  // wavefronts per CU (by an LDS request): at most 24 for the fused kernel (measured best when it needed 63 VGPRs; with the prefix
-  // table it needs 86 and 20 fit anyway); the split form picks per kernel (smem_launch).  ACCG_SMEM_WPC overrides, 0 = no limit.
-  { const char* e = getenv("ACCG_SMEM_WPC"); a.waves_per_cu = e ? (uint32_t)atoi(e) : (b->d_seg ? 0u : 24u); }
+  // wavefronts per CU (by an LDS request): 20 for the fused kernel (what its 88 VGPRs admit; asking for exactly that measures 1-2 %
+  // better than a looser request: 9.19 against 9.35 ms); the split form picks per kernel (smem_launch).  ACCG_SMEM_WPC overrides, 0 = no limit.
+  { const char* e = getenv("ACCG_SMEM_WPC"); a.waves_per_cu = e ? (uint32_t)atoi(e) : (b->d_seg ? 0u : 20u); }
   // ACCG_SMEM_COUNT=1: the counting build of the same kernels (measurement runs only: accg_smem_debug_counts)
   static const bool counting = [] { const char* e = getenv("ACCG_SMEM_COUNT"); return e && e[0] == '1'; }();
   if (b->engine_waves) {

@@ -349,7 +349,7 @@ __device__ __forceinline__ int smem1a_fwd(const Ctx<IT>& f, int len, const Q& q,
     }
     if (i == len) L.curr(n_curr++) = ik;
   }
-  *ret = (int)L.curr(n_curr - 1).lo();
+  *ret = (int)ik.lo();             // = L.curr(n_curr - 1).lo(): every way out of the loops ends with a push of ik as it stands
   return n_curr;
 }
 // Backward half (:219-299): over the n_curr entries of L.curr.
@@ -381,8 +381,11 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
   int k_try = -1, m_done = 0;  // the last winner's k, and the end its interval (`temp`) has been enlarged to
   int b_start = x;             // end of the strings in the back list (set by the last backward chain)
   i = 0;
+  // the entry behind the one in hand is fetched whole where the bookkeeping first wants its end, and is the entry in hand of the
+  // next round (one load per entry instead of three)
+  I c_next = L.curr(0);          // always entry i at the top of the loop
   while (i < n_curr) {
-    const I ci = L.curr(i);
+    const I ci = c_next;
     const int end = (int)ci.lo();
     const bool is_back = n_back == 0 || stop - start >= 3;        // the reference's choice: decides the bookkeeping below
     const int ell = end - x;                                        // bases matched so far (a curr entry starts at x)
@@ -481,7 +484,8 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
       k_found = n_back - 1;
     }
     // the reference's bookkeeping (:242-253 behind "backenlarge", :255 and :270-279 around "forwardenlarge")
-    if (is_back) { start = end; stop = (i == n_curr - 1) ? len : (int)L.curr(i + 1).lo(); }
+    if (i + 1 < n_curr) c_next = L.curr(i + 1);
+    if (is_back) { start = end; stop = (i == n_curr - 1) ? len : (int)c_next.lo(); }
     else stop = end;
     if (k_found >= 0) {
       if (i != 0 && ik.hi() > temp.hi() && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
@@ -489,10 +493,10 @@ __device__ void smem1a_back(const Ctx<IT>& f, int len, const Q& q, int x, int mi
       k_try = k_found; m_done = end;
     }
     i++;
-    if (i < n_curr) max_len = (int)temp.hi() + (int)L.curr(i).lo();
+    if (i < n_curr) max_len = (int)temp.hi() + (int)c_next.lo();
     while (max_len < MIN_SEED_LEN && i < n_curr) {
       i++;
-      if (i < n_curr) stop = (int)L.curr(i).lo();
+      if (i < n_curr) { c_next = L.curr(i); stop = (int)c_next.lo(); }
       max_len = (int)temp.hi() + stop;
     }
     if (i >= n_curr && (int)temp.lo() - (int)temp.hi() >= MIN_SEED_LEN) mem.push(temp);
