@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (fp32 VALU issue, no FMA double count)
 N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32
 PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8,five-op column in gfx950 assembly,two wavefronts per workgroup sharing the dist table>"
-SMEM_KERNEL_NAME = "smem_kernel<uint32_t>"
+SMEM_KERNEL_NAME = "smem_kernel<uint32_t> (first pass + re-seeding) with smem_pass3_kernel<uint32_t> beside it on a second stream, then smem_merge3_kernel: kernel_ms is the whole pass"
 SMEM_SECTOR_PEAK_G = 110.0      # G random 32-byte sectors/s, two dependent sectors per step (tools/ubench_random.hip)
 
 

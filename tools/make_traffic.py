@@ -27,8 +27,9 @@ def entry(k, note=None):
          "fetch_kib": v.get("FETCH_SIZE"), "write_kib": v.get("WRITE_SIZE"), "valu_insts_per_launch": v.get("SQ_INSTS_VALU"),
          "dispatches_seen": v.get("_dispatches_seen"), "counters": {c: v[c] for c in KEEP if c in v}}
     if v.get("SQ_INSTS_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
-        # SQ_THREAD_CYCLES_VALU counts active lanes x 4 cycles per instruction: /4 / insts = mean active lanes of 64
-        e["active_lanes_per_valu_inst"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 4.0
+        # SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = mean active lanes of 64 (62.6 on the PairHMM sweep and 63.2 on the flat SMEM third
+        # pass, whose lanes are all busy by construction)
+        e["active_lanes_per_valu_inst"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]
     if note:
         e["note"] = note
     return e
@@ -43,6 +44,17 @@ if bw:
     bw["valu_insts_per_pass"] = (bw["valu_insts_per_launch"] or 0) * bw_launches
     out["bwasw"] = bw
 out = {k: v for k, v in out.items() if v}
+# round 4: a pass over the SMEM batch is three kernels (fused first pass + re-seeding, the third pass beside it, the merge)
+if "smem_c4" in out:
+    parts = {"smem_pass3": entry("smem_pass3"), "smem_merge3": entry("smem_merge3")}
+    parts = {k: v for k, v in parts.items() if v}
+    if parts:
+        out["smem_c4"]["fused_kernel_hbm_bytes"] = out["smem_c4"]["hbm_bytes_per_launch"]
+        out["smem_c4"]["fused_kernel_valu_insts"] = out["smem_c4"]["valu_insts_per_launch"]
+        out["smem_c4"]["hbm_bytes_per_launch"] += sum(v["hbm_bytes_per_launch"] for v in parts.values())
+        out["smem_c4"]["valu_insts_per_launch"] += sum(v["valu_insts_per_launch"] or 0 for v in parts.values())
+        out["smem_c4"]["note"] = "one pass over 2^20 reads = smem_kernel + smem_pass3_kernel + smem_merge3_kernel; hbm bytes and VALU instructions summed, `counters` are the fused kernel's"
+        out["smem_c4"]["other_kernels"] = parts
 # the kernels of a configs[3] pass (tools/prof_pmc_cmd.sh over tools/run_c3.py 1024: profiles/*_pmc_c3.txt), when measured
 for name in sorted(os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))):
     if not name.endswith("_pmc_c3.txt"):
