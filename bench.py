@@ -40,6 +40,7 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (fp
 N_SIMD, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32
 PHMM_KERNEL_NAME = "phmm_kernel<float,K=13,lanes=8,five-op column in gfx950 assembly,two wavefronts per workgroup sharing the dist table>"
 SMEM_KERNEL_NAME = "smem_kernel<uint32_t> (first pass + re-seeding) with smem_pass3_kernel<uint32_t> beside it on a second stream, then smem_merge3_kernel: kernel_ms is the whole pass"
+SMEM_HBM_RANDOM_PEAK_G = 58.0   # G dependent random 64-byte fetches/s out of a table far beyond the caches (1 GB; tools/ubench_random.hip 1024, profiles/r04_ubench_random.txt)
 SMEM_SECTOR_PEAK_G = 110.0      # G random 32-byte sectors/s, two dependent sectors per step (tools/ubench_random.hip)
 
 
@@ -335,6 +336,13 @@ def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
                                "sectors_32B": {"achieved": ach / 2, "frac": ach / 2 / HBM_PEAK_GBS,
                                                "note": "bytes the re-laid-out index really serves: one 32-byte half-block per Occ lookup"},
                                "random_sectors": random_sectors(sm_tj, lookups_per_read, n_reads, k_ms),
+                               # what the L2 sends on to the fabric per pass (TCC_EA0_RDREQ + WRREQ of the three kernels, profiles/traffic.json;
+                               # 64 bytes each) over this run's pass time, against what HBM gives a bare dependent random-read chase
+                               "hbm_random_requests": (lambda ea: None if not ea else {
+                                   "achieved": (ea["reads"] + ea["writes"]) / (k_ms * 1e-3) / 1e9, "peak": SMEM_HBM_RANDOM_PEAK_G, "unit": "G requests/s",
+                                   "frac": (ea["reads"] + ea["writes"]) / (k_ms * 1e-3) / 1e9 / SMEM_HBM_RANDOM_PEAK_G, "reads_per_pass": ea["reads"], "writes_per_pass": ea["writes"],
+                                   "note": "requests counted in the PMC passes of profiles/ (copied), time of this run; peak = 57-59 G sectors/s out of a 1 GB table "
+                                           "whatever the lanes and the occupancy (profiles/r04_ubench_random.txt); out of a 64 MB table alone in the Infinity Cache: 100-130"})(sm_tj.get("ea_requests_per_pass")),
                                "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
                                        "the path is bound by dependent lookups"})(random_sectors(sm_tj, lookups_per_read, n_reads, k_ms)),
                   "oracle_check": {"reads_checked": S, "equal_to_oracle": smem_ok},

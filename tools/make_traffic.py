@@ -16,7 +16,7 @@ bw_launches = int(sys.argv[2]) if len(sys.argv) > 2 else 18
 d = json.load(open(src))
 KEEP = ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
         "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE",
-        "TCC_HIT_sum", "TCC_MISS_sum")
+        "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum")
 
 
 def entry(k, note=None):
@@ -55,6 +55,11 @@ if "smem_c4" in out:
         out["smem_c4"]["valu_insts_per_launch"] += sum(v["valu_insts_per_launch"] or 0 for v in parts.values())
         out["smem_c4"]["note"] = "one pass over 2^20 reads = smem_kernel + smem_pass3_kernel + smem_merge3_kernel; hbm bytes and VALU instructions summed, `counters` are the fused kernel's"
         out["smem_c4"]["other_kernels"] = parts
+        # requests the L2 sends on (64 bytes each here: FETCH_SIZE / RDREQ), summed over the three kernels of a pass
+        ea = lambda v: (v["counters"].get("TCC_EA0_RDREQ_sum", 0.0), v["counters"].get("TCC_EA0_WRREQ_sum", 0.0))
+        rd = ea(out["smem_c4"])[0] + sum(ea(v)[0] for v in parts.values()); wr = ea(out["smem_c4"])[1] + sum(ea(v)[1] for v in parts.values())
+        if rd:
+            out["smem_c4"]["ea_requests_per_pass"] = {"reads": rd, "writes": wr}
 # the kernels of a configs[3] pass (tools/prof_pmc_cmd.sh over tools/run_c3.py 1024: profiles/*_pmc_c3.txt), when measured
 for name in sorted(os.listdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))):
     if not name.endswith("_pmc_c3.txt"):
