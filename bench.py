@@ -341,7 +341,7 @@ def bench_smem(ctx, comm, steps, with_cpu, genome_bp=67108864, n_reads=1 << 20):
                                "hbm_random_requests": (lambda ea: None if not ea else {
                                    "achieved": (ea["reads"] + ea["writes"]) / (k_ms * 1e-3) / 1e9, "peak": SMEM_HBM_RANDOM_PEAK_G, "unit": "G requests/s",
                                    "frac": (ea["reads"] + ea["writes"]) / (k_ms * 1e-3) / 1e9 / SMEM_HBM_RANDOM_PEAK_G, "reads_per_pass": ea["reads"], "writes_per_pass": ea["writes"],
-                                   "note": "requests counted in the PMC passes of profiles/ (copied), time of this run; peak = 57-59 G sectors/s out of a 1 GB table "
+                                   "note": "a comparison, not a proven bound (DESIGN.md 4b): requests counted in the PMC passes of profiles/ (copied), time of this run; peak = 57-59 G sectors/s out of a 1 GB table "
                                            "whatever the lanes and the occupancy (profiles/r04_ubench_random.txt); out of a 64 MB table alone in the Infinity Cache: 100-130"})(sm_tj.get("ea_requests_per_pass")),
                                "note": "SURVEY 8d unit: one 64-byte BWA block per Occ lookup; the 64 MB index sits in L2 / Infinity Cache, "
                                        "the path is bound by dependent lookups"})(random_sectors(sm_tj, lookups_per_read, n_reads, k_ms)),

@@ -10,7 +10,7 @@
 #include <algorithm>
 
 template <int TWO>
-__global__ __launch_bounds__(64) void chase(const uint4* __restrict__ tab, uint64_t mask, int steps, uint32_t* out, int active, uint4* wbuf, uint64_t wmask) {
+__global__ __launch_bounds__(64) void chase(const uint4* __restrict__ tab, uint64_t mask, int steps, uint32_t* out, int active, uint4* wbuf, uint64_t wmask, int rstream) {
   extern __shared__ uint32_t pad[];
   uint32_t a = blockIdx.x * 64 + threadIdx.x, b = a * 2654435761u + 12345u;
   uint32_t acc = 0;
@@ -24,7 +24,11 @@ __global__ __launch_bounds__(64) void chase(const uint4* __restrict__ tab, uint6
     if (TWO) { b0 = pb[0]; b1 = pb[1]; }
     acc += a0.x ^ a1.y ^ b0.z ^ b1.w;
     // a record of 16 bytes per lane and step into a region that wraps (the SMEM kernel's list pushes: what does a write stream do to the reads' cache?)
-    if (wbuf) wbuf[(((uint64_t)blockIdx.x * steps + s) * 64 + threadIdx.x) & wmask] = make_uint4(acc, a, b, s);
+    if (wbuf) {
+      const uint64_t wi = (((uint64_t)blockIdx.x * steps + s) * 64 + threadIdx.x) & wmask;
+      if (rstream) { const uint4 r = wbuf[(wi + (wmask + 1) / 2) & wmask]; acc += r.x; }      // ... and a record read from the other half of the region (list reads)
+      wbuf[wi] = make_uint4(acc, a, b, s);
+    }
     a = a * 1664525u + 1013904223u + a0.x;     // the next addresses depend on what was read
     b = b * 22695477u + 1u + b1.w;
   }
@@ -38,6 +42,7 @@ int main(int argc, char** argv) {
   const size_t mb = argc > 1 ? strtoull(argv[1], nullptr, 10) : 64;
   const int active = argc > 2 ? atoi(argv[2]) : 64;
   const size_t wmb = argc > 3 ? strtoull(argv[3], nullptr, 10) : 0;       // power of two
+  const int rstream = argc > 4 ? atoi(argv[4]) : 0;
   uint4* wbuf = nullptr; uint64_t wmask = 0;
   if (wmb) { if (hipMalloc(&wbuf, wmb << 20) != hipSuccess) { printf("hipMalloc of the write region failed\n"); return 1; } wmask = ((uint64_t)wmb << 20) / 16 - 1; }
   const size_t bytes = mb << 20, n32 = bytes / 32;
@@ -51,16 +56,16 @@ int main(int argc, char** argv) {
   const int w = 16384, steps = 170;
   hipMalloc(&out, w * 64 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  printf("table of %zu MB, %d of 64 lanes active, write region %zu MB\n", mb, active, wmb);
+  printf("table of %zu MB, %d of 64 lanes active, write region %zu MB%s\n", mb, active, wmb, rstream ? " (and a record read from it per step)" : "");
   const int per_cu[] = {4, 8, 20, 32};
   for (int two = 1; two >= 0; two--)
     for (int wpc : per_cu) {
       const size_t lds = (160 * 1024 / wpc) & ~255u;
       auto k = two ? chase<1> : chase<0>;
       hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(k, dim3(w), dim3(64), lds, 0, tab, (uint64_t)(n32 - 1), steps, out, active, wbuf, wmask);
+      hipLaunchKernelGGL(k, dim3(w), dim3(64), lds, 0, tab, (uint64_t)(n32 - 1), steps, out, active, wbuf, wmask, rstream);
       hipEventRecord(e0);
-      for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k, dim3(w), dim3(64), lds, 0, tab, (uint64_t)(n32 - 1), steps, out, active, wbuf, wmask);
+      for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k, dim3(w), dim3(64), lds, 0, tab, (uint64_t)(n32 - 1), steps, out, active, wbuf, wmask, rstream);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
       const double sectors = (double)w * active * steps * (two ? 2 : 1);
