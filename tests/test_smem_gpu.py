@@ -147,6 +147,27 @@ def test_row_strides_and_third_pass_placement(ctx, stride, aside, monkeypatch):
         assert np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]), k
 
 
+@pytest.mark.parametrize("aside", ["1", "0"])
+def test_batch_in_several_launches(ctx, aside, monkeypatch):
+    """A batch larger than one launch slice (ACCG_SMEM_SLICE): the slices' launches, the third pass beside each and the merge per slice."""
+    monkeypatch.setenv("ACCG_SMEM_PASS3_ASIDE", aside)
+    monkeypatch.setenv("ACCG_SMEM_SLICE", "128")
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 4, size=40000).astype(np.uint8)
+    bwt, para, _ = fmindex.build(g)
+    reads = _reads(rng, g, 333, (20, 255)) + _reads(rng, g, 200, (150, 150), sub=0.01, amb=0.0)
+    seq, ln = fmindex.encode_reads(reads)
+    want, wnum = _oracle(bwt, para, seq, ln, 64)
+    with A.SmemIndex(ctx, bwt, para) as idx, A.SmemBatch(idx, seq, ln, 64) as b:
+        b.run()
+        got, gnum = b.results()
+        b.run()
+        got2, gnum2 = b.results()
+    assert np.array_equal(gnum, wnum) and np.array_equal(gnum2, wnum) and np.array_equal(got, got2)
+    for k in range(len(reads)):
+        assert np.array_equal(got[k, :gnum[k]], want[k, :wnum[k]]), k
+
+
 def test_small_output_slot_counts_but_does_not_store(ctx):
     rng = np.random.default_rng(21)
     g = rng.integers(0, 4, size=20000).astype(np.uint8)
