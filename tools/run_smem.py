@@ -20,6 +20,12 @@ flip = rng.random(N) < 0.5
 reads[flip] = 3 - reads[flip][:, ::-1]
 m = rng.random(reads.shape) < 0.01
 reads[m] = rng.integers(0, 4, size=int(m.sum()))
+if os.environ.get("SMEM_SORT_READS") == "2":     # experiment: reads ordered by WHERE their substitutions are (first, second, third position): the reads of a
+    # wavefront then break their first-pass calls at the same places -- an upper bound for a launch that orders reads by their control flow
+    pos = np.where(m, np.arange(150)[None, :], 150)
+    pos.sort(axis=1)
+    key = pos[:, 0].astype(np.int64) * 151 * 151 + pos[:, 1] * 151 + pos[:, 2]
+    reads = reads[np.argsort(key, kind="stable")]
 if os.environ.get("SMEM_SORT_READS") == "1":     # experiment: reads ordered by their number of substitutions (what a work-ordered launch would see)
     reads = reads[np.argsort(m.sum(axis=1), kind="stable")]
 seq = np.zeros((N, 256), np.uint8); seq[:, :150] = reads
