@@ -32,8 +32,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_no_cpu_fallback_without_device():
+    # (the kernel driver's device node, not torch: in a process whose HIP runtime this library initialised first, torch on the GPU
+    # boxes has been seen to report no device)
     import torch
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd") or torch.cuda.is_available():
         pytest.skip("a GPU is present")
     with pytest.raises(A.AccgError) as e:
         A.Context(0)
